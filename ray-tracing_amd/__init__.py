@@ -1,0 +1,18 @@
+"""MI355X-native renderer for the reference's per-pixel ray-tracing path.
+
+The directory name carries a hyphen; import it with
+    importlib.import_module("ray-tracing_amd")
+or through the `rt355` alias module at the repository root.
+
+Public surface (mirrors what the reference host owns, main.py:96-132 and :244-303):
+    render(scene, camera, w, h, ...) -> uint8 RGB image
+    Camera, CameraController, camera_to_world
+    default_scene, default_camera and the synthetic stress scenes
+"""
+from .camera import Camera, CameraController, camera_to_world, DEFAULT_LIGHT_POS
+from .scenes import (default_scene, default_camera, tori_stress_scene, tori_stress_camera,
+                     spheres_deep_scene, spheres_deep_camera, mixed_scene, mixed_camera)
+
+__all__ = ["Camera", "CameraController", "camera_to_world", "DEFAULT_LIGHT_POS",
+           "default_scene", "default_camera", "tori_stress_scene", "tori_stress_camera",
+           "spheres_deep_scene", "spheres_deep_camera", "mixed_scene", "mixed_camera"]

@@ -1,0 +1,126 @@
+"""Scene lists in the reference's own format, and the synthetic stress scenes.
+
+A scene is the list of dicts the reference keeps in App.scene (main.py:125-132): every
+object has type (1 sphere, 2 torus), center, color, reflectivity, transparency,
+refractive_index; spheres add radius; tori add normal, major_radius, minor_radius.
+`default_scene` / `default_camera` are the reference's shipped values.  The other
+generators are seeded synthetic workloads of the same format (the reference ships only
+the one scene).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .camera import Camera
+
+SHAPE_SPHERE = 1  # fragment_shader.glsl:19
+SHAPE_TORUS = 2   # fragment_shader.glsl:20
+
+
+def default_scene():
+    """main.py:125-132, verbatim values."""
+    return [
+        {"type": 1, "center": [0.0, 0.0, -0.6], "radius": 1.0, "color": [1.0, 1.0, 1.0],
+         "reflectivity": 0.1, "transparency": 0.9, "refractive_index": 1.5},
+        {"type": 1, "center": [-0.5, -0.5, -3.0], "radius": 0.5, "color": [0.2, 1.0, 0.2],
+         "reflectivity": 0.05, "transparency": 0.0, "refractive_index": 1.5},
+        {"type": 1, "center": [0.5, -0.5, -3.0], "radius": 0.5, "color": [0.2, 0.2, 1.0],
+         "reflectivity": 0.05, "transparency": 0.0, "refractive_index": 1.5},
+        {"type": 1, "center": [0.0, 0.366, -3.0], "radius": 0.5, "color": [1.0, 0.2, 0.2],
+         "reflectivity": 0.05, "transparency": 0.0, "refractive_index": 1.5},
+        {"type": 2, "center": [0.0, 1.2, -3.0], "normal": [0.0, 1.0, 0.0], "major_radius": 0.8,
+         "minor_radius": 0.2, "color": [1.0, 0.8, 0.2], "reflectivity": 0.4, "transparency": 0.0,
+         "refractive_index": 1.0},
+    ]
+
+
+def default_camera() -> Camera:
+    """main.py:103-109."""
+    return Camera(eye=(4.0, 1.2, 3.0), yaw=-135.0, pitch=-12.0, focal_length=2.0)
+
+
+def _f32(x):
+    """Round through float32 so every consumer (ctypes, numpy, GL uniforms) sees one value."""
+    return float(np.float32(x))
+
+
+def _vec(v):
+    return [_f32(c) for c in v]
+
+
+def _sphere(center, radius, color, refl, transp, ior):
+    return {"type": SHAPE_SPHERE, "center": _vec(center), "radius": _f32(radius), "color": _vec(color),
+            "reflectivity": _f32(refl), "transparency": _f32(transp), "refractive_index": _f32(ior)}
+
+
+def _torus(center, normal, major, minor, color, refl, transp, ior):
+    return {"type": SHAPE_TORUS, "center": _vec(center), "normal": _vec(normal), "major_radius": _f32(major),
+            "minor_radius": _f32(minor), "color": _vec(color), "reflectivity": _f32(refl),
+            "transparency": _f32(transp), "refractive_index": _f32(ior)}
+
+
+def tori_stress_scene(n: int = 64, seed: int = 355):
+    """Quartic stress: n opaque, reflective tori with random orientations in a long slab."""
+    rng = np.random.default_rng(seed)
+    scene = []
+    for _ in range(n):
+        center = [rng.uniform(-4.0, 4.0), rng.uniform(-0.6, 1.6), rng.uniform(-14.0, 2.0)]
+        normal = rng.normal(size=3)
+        normal /= np.linalg.norm(normal)
+        scene.append(_torus(center, normal, rng.uniform(0.3, 0.6), rng.uniform(0.05, 0.15),
+                            rng.uniform(0.2, 1.0, size=3), 0.3, 0.0, 1.0))
+    return scene
+
+
+def tori_stress_camera() -> Camera:
+    """Low camera looking along the slab so that most rays graze the tori."""
+    return Camera(eye=(0.0, 0.2, 6.0), yaw=-90.0, pitch=-3.0, focal_length=2.0)
+
+
+def spheres_deep_scene(n: int = 256, seed: int = 355):
+    """Deep refraction: half glass spheres (transparency 0.6-0.9, ior 1.5), half mirrors
+    (reflectivity 0.3-0.8)."""
+    rng = np.random.default_rng(seed)
+    scene = []
+    for i in range(n):
+        center = [rng.uniform(-5.0, 5.0), rng.uniform(-0.6, 3.0), rng.uniform(-12.0, -1.0)]
+        radius = rng.uniform(0.2, 0.5)
+        color = rng.uniform(0.2, 1.0, size=3)
+        if i % 2 == 0:
+            scene.append(_sphere(center, radius, color, 0.05, rng.uniform(0.6, 0.9), 1.5))
+        else:
+            scene.append(_sphere(center, radius, color, rng.uniform(0.3, 0.8), 0.0, 1.5))
+    return scene
+
+
+def spheres_deep_camera() -> Camera:
+    return Camera(eye=(0.0, 1.5, 4.0), yaw=-90.0, pitch=-8.0, focal_length=2.0)
+
+
+def mixed_scene(n: int = 1024, seed: int = 355):
+    """Mixed objects: every fourth a torus, the rest spheres; a third of the spheres glass,
+    a third mirrors, a third diffuse."""
+    rng = np.random.default_rng(seed)
+    scene = []
+    for i in range(n):
+        center = [rng.uniform(-10.0, 10.0), rng.uniform(-0.7, 5.0), rng.uniform(-30.0, -1.0)]
+        color = rng.uniform(0.2, 1.0, size=3)
+        if i % 4 == 3:
+            normal = rng.normal(size=3)
+            normal /= np.linalg.norm(normal)
+            scene.append(_torus(center, normal, rng.uniform(0.25, 0.45), rng.uniform(0.05, 0.12),
+                                color, 0.3, 0.0, 1.0))
+        else:
+            radius = rng.uniform(0.15, 0.4)
+            kind = i % 3
+            if kind == 0:
+                scene.append(_sphere(center, radius, color, 0.05, rng.uniform(0.6, 0.9), 1.5))
+            elif kind == 1:
+                scene.append(_sphere(center, radius, color, rng.uniform(0.3, 0.8), 0.0, 1.5))
+            else:
+                scene.append(_sphere(center, radius, color, 0.05, 0.0, 1.5))
+    return scene
+
+
+def mixed_camera() -> Camera:
+    return Camera(eye=(0.0, 2.5, 5.0), yaw=-90.0, pitch=-10.0, focal_length=2.0)
