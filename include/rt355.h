@@ -1,0 +1,141 @@
+/*
+ * rt355.h -- C ABI of librt355.so, the MI355X (gfx950) renderer for the reference's
+ * per-pixel ray-tracing path.
+ *
+ * The reference has no native interface for this path: its boundary is the OpenGL 3.3
+ * uniform block plus one draw call made by App.render (main.py:277-300), and the result
+ * is the window's RGBA8 back buffer (main.py:303).  Each entry point below names the part
+ * of that boundary it replaces.  Plain C types only; every function returns 0 on success
+ * or a negative RT_E_* code, with a message available from rt_last_error().  The library
+ * never aborts the process (the reference calls sys.exit() on shader errors,
+ * main.py:81-84, and raises on link failure, main.py:204-205).
+ *
+ * Threading: one host thread per process drives the library (the reference is single
+ * threaded, main.py:174-178).  Calls are not re-entrant.  One process drives one GPU.
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MAX_OBJECTS 1024   /* scene objects per frame (LDS-resident)                 */
+#define RT_MAX_PENDING 16     /* min(stack_size, max_depth-1) must not exceed this       */
+#define RT_BAND_ROWS   16     /* rows per screen band when a frame is split over GPUs    */
+
+enum {
+    RT_OK = 0,
+    RT_E_ARG = -1,        /* null pointer, bad size, bad enum                           */
+    RT_E_SCENE = -2,      /* object type not 1/2, non-finite value, too many objects    */
+    RT_E_LIMIT = -3,      /* stack/depth/spp beyond what the kernels are built for      */
+    RT_E_STATE = -4,      /* rt_init not called / no scene set                          */
+    RT_E_HIP = -5,        /* a HIP runtime call failed                                  */
+    RT_E_SIZE = -6        /* output buffer too small                                    */
+};
+
+/* Mirrors `struct SceneObject` (fragment_shader.glsl:41-56) field for field, 64 bytes.
+ * Filled from the scene dict list the way main.py:283-296 uploads it: a sphere leaves
+ * normal/major_radius/minor_radius at 0, a torus leaves radius at 0.                     */
+typedef struct rt_object {
+    int32_t type;               /* 1 = sphere, 2 = torus (fragment_shader.glsl:19-20)    */
+    float center[3];
+    float radius;
+    float normal[3];
+    float major_radius;
+    float minor_radius;
+    float color[3];
+    float reflectivity;
+    float transparency;
+    float refractive_index;
+} rt_object;
+
+enum {
+    RT_FLAG_FAST_MATH     = 1u << 0,  /* contracted FMA + hardware rcp/rsq/sqrt/exp/log; default is
+                                         the strict flavour whose arithmetic equals the reference
+                                         shader's as executed by llvmpipe                           */
+    RT_FLAG_NEWTON_POLISH = 1u << 1,  /* two Newton steps on the selected torus root               */
+    RT_FLAG_BOTTOM_UP     = 1u << 2,  /* rows in GL order (row 0 = bottom); default row 0 = top     */
+    RT_FLAG_OUT_F32       = 1u << 3   /* write float RGBA (unclamped, alpha 1) instead of RGBA8     */
+};
+
+/* The uniforms of fragment_shader.glsl:12-15 as main.py:277-280 sets them, plus the
+ * constants the shader hard-codes, as run-time parameters.                               */
+typedef struct rt_params {
+    float cam_to_world[16];     /* row-major 4x4, rows [x|y|view|eye] as main.py:269-274 builds
+                                   it (uploaded there with transpose=GL_TRUE, main.py:279)        */
+    float focal_length;         /* u_focal_length, main.py:280                                    */
+    float light_pos[3];         /* u_light_pos, main.py:278                                       */
+    int32_t width, height;      /* u_resolution, main.py:277                                      */
+    int32_t max_depth;          /* fragment_shader.glsl:653 (4)                                   */
+    int32_t stack_size;         /* fragment_shader.glsl:547 (3)                                   */
+    int32_t shadow_hops;        /* fragment_shader.glsl:453 (2)                                   */
+    int32_t spp_grid;           /* N: N x N stratified samples per pixel, averaged before the
+                                   framebuffer clamp; 1 = the reference's single centre sample    */
+    uint32_t flags;             /* RT_FLAG_*                                                      */
+    int32_t part, nparts;       /* screen-space split: this call renders the bands b (RT_BAND_ROWS
+                                   rows each, counted from the top of the image) with
+                                   b % nparts == part, packed in band order; 0,1 = whole frame    */
+} rt_params;
+
+typedef struct rt_timing {
+    float kernel_ms;            /* last render kernel, hipEvent-timed on its stream               */
+    float total_ms;             /* last rt_render call incl. upload and read-back (host clock)    */
+    int32_t vgprs, lds_bytes;   /* resources of the kernel variant that ran                       */
+    int32_t pending_cap;        /* register-resident pending-ray slots of that variant            */
+} rt_timing;
+
+/* Replaces context/program creation (main.py:134-161, :195-208): binds the process to
+ * one GPU, creates the render stream and loads the kernels.                              */
+int rt_init(int device);
+
+/* Replaces cleanup (main.py:350-355).                                                    */
+void rt_shutdown(void);
+
+const char *rt_last_error(void);
+
+/* Replaces the per-object glUniform* upload (main.py:283-296): validates, derives the
+ * per-object invariants (bounding radius^2, torus frame) and stages the scene on the GPU.
+ * The scene stays current until the next call.                                           */
+int rt_set_scene(const rt_object *objs, int n);
+
+/* Bytes a render with these parameters writes (the packed bands of `part`).             */
+size_t rt_output_bytes(const rt_params *p);
+
+/* Replaces glUniform*(camera) + glDrawArrays (main.py:277-280, :300) for a caller that
+ * owns device memory: renders the current scene into `d_out` (device pointer) on
+ * `stream` (a hipStream_t, or NULL for the library's stream) without synchronising.
+ * With timed != 0 the kernel is bracketed by hipEvents read back by rt_get_timing.       */
+int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed);
+
+/* Convenience for host callers: rt_set_scene + render + copy to `out` (host memory),
+ * blocking.  This is the call that stands where App.render's draw stood (main.py:244-303). */
+int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_t out_bytes);
+
+/* After a split render: `d_gathered` holds the nparts packed buffers back to back in part
+ * order (what a gather to GPU 0 delivers); writes the assembled frame to `d_image`.       */
+int rt_assemble_device(const void *d_gathered, void *d_image, int width, int height,
+                       int nparts, int bytes_per_pixel, void *stream);
+
+int rt_get_timing(rt_timing *t);
+
+/* Work accounting: runs the instrumented flavour of the same kernel over the frame and
+ * returns one counter per event class (rt_event_count() of them); rt_event_flops(i) is the
+ * number of scalar FP32 operations the reference shader source spends on one event i.    */
+int rt_count_events(const rt_params *p, uint64_t *events);
+int rt_event_count(void);
+int rt_event_flops(int event);
+const char *rt_event_name(int event);
+
+/* Parity instrumentation: for the seg-th ray of every pixel-centre path in visit order
+ * (0 = primary) writes 4 floats per pixel to `out` (host): object id (-1 sky, 0..n-1 scene
+ * object, n ground plane, -2 no such segment), t, depth, number of segments of the path.  */
+int rt_capture_segment(const rt_params *p, int seg, float *out, size_t out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

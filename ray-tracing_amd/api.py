@@ -1,0 +1,251 @@
+"""Python host over the C ABI of librt355.so (include/rt355.h).
+
+`render(scene, camera, w, h)` stands where the reference's App.render stood
+(main.py:244-303): it takes the same scene list (main.py:125-132) and the same camera
+state (main.py:102-109), computes the camera matrix the way main.py:253-274 does and hands
+everything to the HIP kernels.  There is no CPU fallback: if the library or a GPU is
+missing the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from .camera import Camera
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "librt355.so")
+
+RT_MAX_OBJECTS = 1024
+RT_MAX_PENDING = 16
+RT_BAND_ROWS = 16
+
+FLAG_FAST_MATH = 1 << 0
+FLAG_NEWTON_POLISH = 1 << 1
+FLAG_BOTTOM_UP = 1 << 2
+FLAG_OUT_F32 = 1 << 3
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librt355 error {code}: {msg}")
+        self.code = code
+
+
+class RtObject(ctypes.Structure):
+    """struct rt_object == struct SceneObject (fragment_shader.glsl:41-56)."""
+    _fields_ = [("type", ctypes.c_int32), ("center", ctypes.c_float * 3), ("radius", ctypes.c_float),
+                ("normal", ctypes.c_float * 3), ("major_radius", ctypes.c_float), ("minor_radius", ctypes.c_float),
+                ("color", ctypes.c_float * 3), ("reflectivity", ctypes.c_float),
+                ("transparency", ctypes.c_float), ("refractive_index", ctypes.c_float)]
+
+
+class RtParams(ctypes.Structure):
+    _fields_ = [("cam_to_world", ctypes.c_float * 16), ("focal_length", ctypes.c_float),
+                ("light_pos", ctypes.c_float * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("max_depth", ctypes.c_int32), ("stack_size", ctypes.c_int32), ("shadow_hops", ctypes.c_int32),
+                ("spp_grid", ctypes.c_int32), ("flags", ctypes.c_uint32), ("part", ctypes.c_int32),
+                ("nparts", ctypes.c_int32)]
+
+
+class RtTiming(ctypes.Structure):
+    _fields_ = [("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("vgprs", ctypes.c_int32),
+                ("lds_bytes", ctypes.c_int32), ("pending_cap", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(RtObject) == 64
+
+_lib = None
+_inited_device = None
+
+EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
+           "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
+           "rt_event_flops", "rt_event_name", "rt_capture_segment"]
+
+
+def load_library():
+    """dlopen librt355.so and declare its prototypes.  No GPU is touched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(-4, f"{LIB_PATH} is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.rt_init.argtypes = [ci]
+    L.rt_shutdown.restype = None
+    L.rt_last_error.restype = ctypes.c_char_p
+    L.rt_set_scene.argtypes = [vp, ci]
+    L.rt_output_bytes.restype = sz
+    L.rt_output_bytes.argtypes = [vp]
+    L.rt_render_device.argtypes = [vp, vp, sz, vp, ci]
+    L.rt_render.argtypes = [vp, ci, vp, vp, sz]
+    L.rt_assemble_device.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    L.rt_get_timing.argtypes = [vp]
+    L.rt_count_events.argtypes = [vp, vp]
+    L.rt_event_flops.argtypes = [ci]
+    L.rt_event_name.argtypes = [ci]
+    L.rt_event_name.restype = ctypes.c_char_p
+    L.rt_capture_segment.argtypes = [vp, ci, vp, sz]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, _lib.rt_last_error().decode(errors="replace"))
+
+
+def init(device: int = 0):
+    """rt_init: bind this process to one GPU (one process per GPU)."""
+    global _inited_device
+    L = load_library()
+    _check(L.rt_init(int(device)))
+    _inited_device = int(device)
+    return L
+
+
+def _ensure_init():
+    if _inited_device is None:
+        init(int(os.environ.get("LOCAL_RANK", "0")))
+    return _lib
+
+
+def shutdown():
+    global _inited_device
+    if _lib is not None and _inited_device is not None:
+        _lib.rt_shutdown()
+    _inited_device = None
+
+
+_SCENE_KEYS = {"type", "center", "radius", "normal", "major_radius", "minor_radius", "color", "reflectivity",
+               "transparency", "refractive_index"}
+
+
+def pack_scene(scene):
+    """Scene list (dicts as in main.py:125-132) -> ctypes array of rt_object.  As in the
+    reference's upload loop (main.py:283-296) a sphere only sets radius and a torus only sets
+    normal/major_radius/minor_radius; the other geometric fields stay 0."""
+    if len(scene) > RT_MAX_OBJECTS:
+        raise RtError(-2, f"{len(scene)} objects exceed the limit of {RT_MAX_OBJECTS}")
+    arr = (RtObject * max(len(scene), 1))()
+    for i, o in enumerate(scene):
+        unknown = set(o) - _SCENE_KEYS
+        if unknown:
+            raise RtError(-2, f"object {i}: unknown keys {sorted(unknown)}")
+        a = arr[i]
+        try:
+            a.type = int(o["type"])
+            a.center[:] = [float(v) for v in o["center"]]
+            a.color[:] = [float(v) for v in o["color"]]
+            a.reflectivity = float(o["reflectivity"])
+            a.transparency = float(o["transparency"])
+            a.refractive_index = float(o["refractive_index"])
+            if a.type == 1:
+                a.radius = float(o["radius"])
+            elif a.type == 2:
+                a.normal[:] = [float(v) for v in o["normal"]]
+                a.major_radius = float(o["major_radius"])
+                a.minor_radius = float(o["minor_radius"])
+        except KeyError as e:
+            raise RtError(-2, f"object {i}: missing key {e}") from None
+    return arr
+
+
+def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1, flags=0,
+                part=0, nparts=1) -> RtParams:
+    cam = Camera.coerce(camera)
+    p = RtParams()
+    p.cam_to_world[:] = cam.matrix().ravel().tolist()
+    p.focal_length = float(cam.focal_length)
+    p.light_pos[:] = [float(v) for v in cam.light_pos]
+    p.width, p.height = int(w), int(h)
+    p.max_depth, p.stack_size, p.shadow_hops, p.spp_grid = int(max_depth), int(stack_size), int(shadow_hops), int(spp_grid)
+    p.flags = int(flags)
+    p.part, p.nparts = int(part), int(nparts)
+    return p
+
+
+def _flags(fast_math, newton_polish, bottom_up, out_f32):
+    return ((FLAG_FAST_MATH if fast_math else 0) | (FLAG_NEWTON_POLISH if newton_polish else 0) |
+            (FLAG_BOTTOM_UP if bottom_up else 0) | (FLAG_OUT_F32 if out_f32 else 0))
+
+
+def set_scene(scene):
+    L = _ensure_init()
+    arr = pack_scene(scene)
+    _check(L.rt_set_scene(ctypes.addressof(arr), len(scene)))
+
+
+def render_rgba(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
+                fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1):
+    """Render and return (rows, w, 4): uint8 RGBA as the reference's RGBA8 back buffer would
+    hold it (main.py:303), or float32 unclamped colour with out_f32.  Row 0 is the TOP row
+    unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands."""
+    L = _ensure_init()
+    arr = pack_scene(scene)
+    p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
+                    spp_grid=spp_grid, flags=_flags(fast_math, newton_polish, bottom_up, out_f32),
+                    part=part, nparts=nparts)
+    nbytes = L.rt_output_bytes(ctypes.addressof(p))
+    bpp = 16 if out_f32 else 4
+    rows = nbytes // (bpp * int(w)) if w > 0 else 0
+    out = np.empty((rows, int(w), 4), dtype=np.float32 if out_f32 else np.uint8)
+    _check(L.rt_render(ctypes.addressof(arr), len(scene), ctypes.addressof(p), out.ctypes.data, out.nbytes))
+    return out
+
+
+def render(scene, camera, w, h, **opts) -> np.ndarray:
+    """render(scene, camera, w, h) -> (h, w, 3) uint8 RGB, row 0 = top of the image.
+
+    scene : list of dicts exactly as the reference's App.scene (main.py:125-132)
+    camera: Camera or dict(eye, yaw, pitch, focal_length[, light_pos]) (main.py:102-109, :278)
+    opts  : max_depth=4, stack_size=3, shadow_hops=2 (the constants of fragment_shader.glsl:653,
+            :547, :453), spp_grid=1, fast_math=False, newton_polish=False
+    """
+    return np.ascontiguousarray(render_rgba(scene, camera, w, h, **opts)[..., :3])
+
+
+def timing() -> dict:
+    L = _ensure_init()
+    t = RtTiming()
+    _check(L.rt_get_timing(ctypes.addressof(t)))
+    return {"kernel_ms": t.kernel_ms, "total_ms": t.total_ms, "vgprs": t.vgprs, "lds_bytes": t.lds_bytes,
+            "pending_cap": t.pending_cap}
+
+
+def event_table():
+    L = load_library()
+    n = L.rt_event_count()
+    return [L.rt_event_name(i).decode() for i in range(n)], np.array([L.rt_event_flops(i) for i in range(n)], dtype=np.int64)
+
+
+def count_events(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1, fast_math=False):
+    """Per-frame work counters (uint64 per event class) from the instrumented kernel flavour."""
+    L = _ensure_init()
+    set_scene(scene)
+    p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
+                    spp_grid=spp_grid, flags=_flags(fast_math, False, False, False))
+    ev = np.zeros(L.rt_event_count(), dtype=np.uint64)
+    _check(L.rt_count_events(ctypes.addressof(p), ev.ctypes.data))
+    return ev
+
+
+def capture_segment(scene, camera, w, h, seg, *, max_depth=4, stack_size=3, shadow_hops=2, fast_math=False,
+                    bottom_up=True):
+    """(h, w, 4) float32: object id, t, depth, segment count for segment `seg` of each path."""
+    L = _ensure_init()
+    set_scene(scene)
+    p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
+                    flags=_flags(fast_math, False, bottom_up, False))
+    out = np.empty((int(h), int(w), 4), dtype=np.float32)
+    _check(L.rt_capture_segment(ctypes.addressof(p), int(seg), out.ctypes.data, out.nbytes))
+    return out
+
+
+def frame_flops(events) -> int:
+    """Algorithmic FLOPs of a frame: sum over event classes of count x per-event FLOPs."""
+    _, table = event_table()
+    return int((np.asarray(events, dtype=np.int64) * table).sum())

@@ -1,0 +1,405 @@
+// rt_api.hip -- host side of librt355.so: the C ABI declared in include/rt355.h.
+//
+// Takes over what App.render does between the scene list and the back buffer
+// (main.py:277-303): parameter validation, per-object invariants, scene staging on the
+// GPU, kernel launch, read-back.  Host arithmetic that feeds the kernels is plain binary32
+// with no contraction (this file is built with -ffp-contract=off) so that the derived
+// per-object values are the ones the reference shader computes per ray.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt355.h"
+#include "rt_types.h"
+
+namespace {
+
+struct State {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+    float *d_scene = nullptr;
+    size_t d_scene_cap = 0;
+    SceneLayout layout{};
+    bool have_scene = false;
+    void *d_out = nullptr;          // staging for rt_render / debug launches
+    size_t d_out_cap = 0;
+    unsigned long long *d_events = nullptr;
+    rt_timing timing{};
+    char err[512] = "";
+} g;
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g.err, sizeof g.err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail(RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// dot/normalize in the reference's operation order (z, y, then x; v * (1/sqrt(dot)))
+inline float dot3(const float *a, const float *b) { return (a[2] * b[2] + a[1] * b[1]) + a[0] * b[0]; }
+inline void normalize3(float *v)
+{
+    float r = 1.0f / std::sqrt(dot3(v, v));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+inline void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+int ensure_out(size_t bytes)
+{
+    if (bytes <= g.d_out_cap) return 0;
+    if (g.d_out) HIP_TRY(hipFree(g.d_out));
+    g.d_out = nullptr; g.d_out_cap = 0;
+    HIP_TRY(hipMalloc(&g.d_out, bytes));
+    g.d_out_cap = bytes;
+    return 0;
+}
+
+int validate_params(const rt_params *p)
+{
+    if (!p) return fail(RT_E_ARG, "params is null");
+    if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
+        return fail(RT_E_ARG, "resolution %dx%d out of range", p->width, p->height);
+    if (p->max_depth < 1) return fail(RT_E_ARG, "max_depth must be >= 1");
+    if (p->stack_size < 1) return fail(RT_E_ARG, "stack_size must be >= 1");
+    if (p->shadow_hops < 0 || p->shadow_hops > 64) return fail(RT_E_ARG, "shadow_hops out of range");
+    if (p->spp_grid < 1 || p->spp_grid > 16) return fail(RT_E_LIMIT, "spp_grid must be 1..16");
+    int need = p->stack_size < p->max_depth - 1 ? p->stack_size : p->max_depth - 1;
+    if (need > RT_MAX_PENDING)
+        return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d register-resident pending rays",
+                    need, RT_MAX_PENDING);
+    if (p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return fail(RT_E_ARG, "bad part/nparts");
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(p->cam_to_world[i])) return fail(RT_E_ARG, "camera matrix is not finite");
+    if (!std::isfinite(p->focal_length)) return fail(RT_E_ARG, "focal length is not finite");
+    return 0;
+}
+
+int part_rows(const rt_params *p)
+{
+    int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+    int rows = 0;
+    for (int b = p->part; b < bands; b += p->nparts) {
+        int r0 = b * RT_BAND_ROWS;
+        int r1 = r0 + RT_BAND_ROWS < p->height ? r0 + RT_BAND_ROWS : p->height;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+KParams make_kparams(const rt_params *p)
+{
+    KParams k{};
+    const float *m = p->cam_to_world;
+    // columns of the matrix as the shader sees it after the transposed upload
+    for (int r = 0; r < 3; ++r) {
+        k.right[r] = m[4 * r + 0];
+        k.up[r] = m[4 * r + 1];
+        k.fwd[r] = m[4 * r + 2];
+        k.eye[r] = m[4 * r + 3];
+    }
+    k.focal = p->focal_length;
+    for (int i = 0; i < 3; ++i) k.light[i] = p->light_pos[i];
+    k.res_w = (float)p->width; k.res_h = (float)p->height;
+    k.w = p->width; k.h = p->height;
+    k.max_depth = p->max_depth; k.stack_size = p->stack_size; k.hops = p->shadow_hops; k.spp = p->spp_grid;
+    k.bottom_up = (p->flags & RT_FLAG_BOTTOM_UP) ? 1 : 0;
+    k.part = p->part; k.nparts = p->nparts;
+    k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
+    k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
+    k.capture_seg = -1;
+    k.scene = g.layout;
+    return k;
+}
+
+const char *const k_event_names[EV_COUNT] = {
+    "pixel_path", "trace", "bound_cull_disc", "bound_tbound", "bound_torus_radius",
+    "sphere_call", "sphere_root", "sphere_hit", "plane_call", "plane_t", "plane_hit",
+    "torus_call", "quad_full", "quad_early", "biq_z", "root_out", "cubic", "cardano", "trig",
+    "ferrari_tail", "torus_hit", "seg_miss", "seg_hit", "fresnel_tir", "fresnel_full", "local",
+    "phong_shadowed", "phong_full", "atten_fixed", "hop_hit_test", "hop_filter", "hop_continue",
+    "refr_try", "refr_push", "refl_eval", "refl_push", "drop"};
+
+// Scalar FP32 operations of the reference shader source per event: add/sub/mul/div/sqrt/
+// inversesqrt/floor/min/max/mod/pow/cos/acos count 1; compare/negate/abs/sign/select 0;
+// dot3 5, cross 9, normalize 9, length 6, reflect 12, refract 22, mix(vec3) 9, clamp 2.
+const int k_event_flops[EV_COUNT] = {
+    30, 0, 17, 19, 1,        // main() :652-668; bounding test :399-410; torus radius :395
+    25, 4, 18,               // intersect_sphere :77-81, :87/:89, :95-96
+    5, 2, 10,                // intersect_plane :116, :118, :124/:137
+    131, 11, 4, 2, 1,        // intersect_torus set-up + quartic depress :314-339/:252-256; solve_quadratic
+    26, 10, 23, 9, 54,       // resolvent + solve_cubic :281/:201-215; Cardano; trig; Ferrari tail; torus hit :359-367
+    17, 12, 9, 14, 9,        // sky :575-578; hit common; Fresnel TIR / full :525-533; local accumulate :603
+    8, 73, 39, 1, 11, 7,     // phong shadowed / full :490-513; attenuation :443-448, :457, :462-468, :473-474
+    28, 16, 3, 21, 0};       // refraction :613-620; reflection :629-637; drops
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g.err; }
+
+int rt_init(int device)
+{
+    if (g.inited) {
+        if (device == g.device) return RT_OK;
+        return fail(RT_E_STATE, "already initialised on device %d; one process drives one GPU", g.device);
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RT_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(RT_E_ARG, "device %d out of range (0..%d)", device, count - 1);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
+    g.device = device;
+    g.inited = true;
+    g.err[0] = 0;
+    return RT_OK;
+}
+
+void rt_shutdown(void)
+{
+    if (!g.inited) return;
+    hipSetDevice(g.device);
+    hipStreamSynchronize(g.stream);
+    if (g.d_scene) hipFree(g.d_scene);
+    if (g.d_out) hipFree(g.d_out);
+    if (g.d_events) hipFree(g.d_events);
+    hipEventDestroy(g.ev0);
+    hipEventDestroy(g.ev1);
+    hipStreamDestroy(g.stream);
+    g = State{};
+}
+
+int rt_set_scene(const rt_object *objs, int n)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (n < 0 || (n > 0 && !objs)) return fail(RT_E_ARG, "bad scene pointer/count");
+    if (n > RT_MAX_OBJECTS) return fail(RT_E_SCENE, "%d objects exceed the limit of %d", n, RT_MAX_OBJECTS);
+    int ntori = 0;
+    for (int i = 0; i < n; ++i) {
+        const rt_object &o = objs[i];
+        // any other type reads an uninitialised HitInfo in the reference (fragment_shader.glsl:416-421)
+        if (o.type != 1 && o.type != 2) return fail(RT_E_SCENE, "object %d: type %d is not 1 (sphere) or 2 (torus)", i, o.type);
+        const float *f = &o.center[0];
+        for (int k = 0; k < 15; ++k)
+            if (!std::isfinite(f[k])) return fail(RT_E_SCENE, "object %d: field %d is not finite", i, k + 1);
+        if (o.type == 2) ntori++;
+    }
+    SceneLayout L = scene_layout(n, ntori);
+    std::vector<float> blob((size_t)L.total_dwords + 4, 0.0f);
+    int *kind = reinterpret_cast<int *>(blob.data() + L.off_kind);
+    int slot = 0;
+    for (int i = 0; i < n; ++i) {
+        const rt_object &o = objs[i];
+        // bounding radius: radius, or major + minor for a torus (fragment_shader.glsl:391-396)
+        float br = o.type == 1 ? o.radius : o.major_radius + o.minor_radius;
+        float *b = blob.data() + 4 * i;
+        b[0] = o.center[0]; b[1] = o.center[1]; b[2] = o.center[2]; b[3] = br * br;
+        float *m = blob.data() + L.off_material + 8 * i;
+        m[0] = o.color[0]; m[1] = o.color[1]; m[2] = o.color[2]; m[3] = o.reflectivity;
+        m[4] = o.transparency; m[5] = o.refractive_index;
+        if (o.type == 1) { kind[i] = -1; continue; }
+        kind[i] = slot;
+        // torus frame (fragment_shader.glsl:315-317): w = normalize(normal),
+        // u = normalize(cross(w, |w.y| > 0.99 ? (1,0,0) : (0,1,0))), v = cross(w, u)
+        float w[3] = {o.normal[0], o.normal[1], o.normal[2]};
+        normalize3(w);
+        float sel = std::fabs(w[1]) > 0.99f ? 1.0f : 0.0f;
+        float helper[3] = {sel, 1.0f - sel, 0.0f};
+        float u[3], v[3];
+        cross3(w, helper, u);
+        normalize3(u);
+        cross3(w, u, v);
+        float R = o.major_radius, r = o.minor_radius;
+        float *t = blob.data() + L.off_torus + 16 * slot;
+        t[0] = u[0]; t[1] = u[1]; t[2] = u[2]; t[3] = w[0];
+        t[4] = w[1]; t[5] = w[2]; t[6] = v[0]; t[7] = v[1];
+        t[8] = v[2]; t[9] = R; t[10] = R * R; t[11] = r * r;
+        t[12] = (4.0f * R) * R; t[13] = (8.0f * R) * R;
+        slot++;
+    }
+    size_t bytes = (size_t)L.total_dwords * sizeof(float);
+    if (bytes < 16) bytes = 16;
+    if (bytes > g.d_scene_cap) {
+        if (g.d_scene) HIP_TRY(hipFree(g.d_scene));
+        g.d_scene = nullptr; g.d_scene_cap = 0;
+        size_t cap = bytes < 4096 ? 4096 : bytes;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_scene), cap));
+        g.d_scene_cap = cap;
+    }
+    // blocking copy: later launches on any stream see the new scene
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
+    g.layout = L;
+    g.have_scene = true;
+    return RT_OK;
+}
+
+size_t rt_output_bytes(const rt_params *p)
+{
+    if (!p || p->width <= 0 || p->height <= 0 || p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return 0;
+    size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : 4;
+    return (size_t)part_rows(p) * (size_t)p->width * bpp;
+}
+
+int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (!g.have_scene) return fail(RT_E_STATE, "no scene set (rt_set_scene)");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    size_t need = rt_output_bytes(p);
+    if (!d_out && need) return fail(RT_E_ARG, "output pointer is null");
+    if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    KParams kp = make_kparams(p);
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
+    LaunchInfo info{};
+    if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
+    int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)
+                                             : rt_strict::launch_render(kp, g.d_scene, d_out, s, &info);
+    if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (timed) { HIP_TRY(hipEventRecord(g.ev1, s)); g.ev_pending = true; }
+    g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap;
+    return RT_OK;
+}
+
+int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_t out_bytes)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = rt_set_scene(objs, n);
+    if (rc) return rc;
+    rc = validate_params(p);
+    if (rc) return rc;
+    size_t need = rt_output_bytes(p);
+    if (!out && need) return fail(RT_E_ARG, "output pointer is null");
+    if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    rc = ensure_out(need);
+    if (rc) return rc;
+    rc = rt_render_device(p, g.d_out, need, g.stream, 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, g.d_out, need, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_get_timing(rt_timing *t)
+{
+    if (!t) return fail(RT_E_ARG, "timing pointer is null");
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (g.ev_pending) {
+        HIP_TRY(hipEventSynchronize(g.ev1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        g.timing.kernel_ms = ms;
+        g.ev_pending = false;
+    }
+    *t = g.timing;
+    return RT_OK;
+}
+
+int rt_event_count(void) { return EV_COUNT; }
+int rt_event_flops(int ev) { return (ev >= 0 && ev < EV_COUNT) ? k_event_flops[ev] : -1; }
+const char *rt_event_name(int ev) { return (ev >= 0 && ev < EV_COUNT) ? k_event_names[ev] : ""; }
+
+static int debug_launch(const rt_params *p, int seg, uint64_t *events, float *cap_host, size_t cap_bytes)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (!g.have_scene) return fail(RT_E_STATE, "no scene set (rt_set_scene)");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    KParams kp = make_kparams(p);
+    kp.capture_seg = seg;
+    size_t need_cap = 0;
+    float *d_cap = nullptr;
+    if (cap_host) {
+        need_cap = (size_t)part_rows(p) * p->width * 4 * sizeof(float);
+        if (cap_bytes < need_cap) return fail(RT_E_SIZE, "capture buffer holds %zu bytes, %zu needed", cap_bytes, need_cap);
+        rc = ensure_out(need_cap);
+        if (rc) return rc;
+        d_cap = reinterpret_cast<float *>(g.d_out);
+    }
+    HIP_TRY(hipMemsetAsync(g.d_events, 0, EV_COUNT * sizeof(unsigned long long), g.stream));
+    int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_debug(kp, g.d_scene, g.d_events, d_cap, g.stream)
+                                             : rt_strict::launch_debug(kp, g.d_scene, g.d_events, d_cap, g.stream);
+    if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (events)
+        HIP_TRY(hipMemcpyAsync(events, g.d_events, EV_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
+    if (cap_host) HIP_TRY(hipMemcpyAsync(cap_host, d_cap, need_cap, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RT_OK;
+}
+
+int rt_count_events(const rt_params *p, uint64_t *events)
+{
+    if (!events) return fail(RT_E_ARG, "events pointer is null");
+    return debug_launch(p, -1, events, nullptr, 0);
+}
+
+int rt_capture_segment(const rt_params *p, int seg, float *out, size_t out_bytes)
+{
+    if (!out) return fail(RT_E_ARG, "output pointer is null");
+    if (seg < 0) return fail(RT_E_ARG, "segment index must be >= 0");
+    return debug_launch(p, seg, nullptr, out, out_bytes);
+}
+
+// Kernel that scatters the gathered per-part band buffers into the final frame.
+__global__ void assemble_kernel(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ image, int width_dw,
+                                int height, int nparts, size_t part_stride_dw)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = blockIdx.y;
+    if (x >= width_dw || row >= height) return;
+    int band = row / RT_BAND_ROWS;
+    int part = band % nparts;
+    int local_band = band / nparts;
+    size_t src_row = (size_t)local_band * RT_BAND_ROWS + (row - band * RT_BAND_ROWS);
+    image[(size_t)row * width_dw + x] = gathered[part * part_stride_dw + src_row * width_dw + x];
+}
+
+int rt_assemble_device(const void *d_gathered, void *d_image, int width, int height, int nparts,
+                       int bytes_per_pixel, void *stream)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (!d_gathered || !d_image || width <= 0 || height <= 0 || nparts < 1 || (bytes_per_pixel != 4 && bytes_per_pixel != 16))
+        return fail(RT_E_ARG, "bad assemble arguments");
+    // every part's buffer is padded to the size of part 0 (the largest), as a gather of
+    // equal-sized chunks delivers them
+    rt_params p0{};
+    p0.width = width; p0.height = height; p0.part = 0; p0.nparts = nparts;
+    size_t stride_dw = (size_t)part_rows(&p0) * width * (bytes_per_pixel / 4);
+    int width_dw = width * (bytes_per_pixel / 4);
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
+    dim3 grid((width_dw + 255) / 256, height);
+    hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint32_t *>(d_gathered),
+                       reinterpret_cast<uint32_t *>(d_image), width_dw, height, nparts, stride_dw);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"

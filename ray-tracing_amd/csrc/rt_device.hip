@@ -1,0 +1,801 @@
+// rt_device.hip -- the gfx950 render kernel.
+//
+// Compiled twice into one library:
+//   strict flavour (default):  -ffp-contract=off, correctly rounded / and sqrt, the
+//       reference shader's transcendental kernels restated with explicit fma.  Every FP32
+//       operation is the one llvmpipe executes for fragment_shader.glsl, in its order, so the
+//       frame is bit-identical to the reference's.
+//   fast flavour (-DRT_FAST):  -ffp-contract=fast plus v_rcp/v_rsq/v_sqrt/v_exp/v_log/v_cos.
+// Both are the same source; the flavour only changes the primitives in the "numerics" block.
+//
+// Design (wave64, VALU-bound, no MFMA: there is no dense contraction in this workload):
+//   * one lane = one pixel; a wave owns an 8x8 pixel tile, a 256-thread workgroup 16x16.
+//   * the scene is staged once per workgroup in LDS, split so that the per-object hot loop
+//     reads one 16-byte record (centre + bounding radius^2) as an LDS broadcast; torus
+//     frames, kinds and materials sit behind the bounding test / the closest-hit decision.
+//   * trace() keeps only (t, id) of the closest hit; position, normal and material are
+//     derived once for the winner (the reference builds a full HitInfo per candidate,
+//     fragment_shader.glsl:416-425; only the winner's is ever read).
+//   * the reference's explicit ray stack (fragment_shader.glsl:547-564) is held in
+//     registers as "current ray + pending refraction rays": the reflection child is always
+//     popped right after it is pushed, so it never needs a slot; slots are addressed with
+//     compare/select chains (no dynamic register indexing, no scratch memory).  Visit order
+//     and the silent drop rule (stack_ptr < STACK_SIZE, :615/:632) are preserved exactly.
+//   * path rays and shadow rays go through ONE trace site: each lane is a small state
+//     machine (PATH / SHADOW), so lanes shading and lanes casting shadow rays share the
+//     wave's trace iterations instead of serialising two inlined copies of trace().
+//   * a lane that finishes a sample starts its next stratified sample immediately.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_types.h"
+
+#ifdef RT_FAST
+#define RT_NS rt_fast
+#else
+#define RT_NS rt_strict
+#endif
+
+namespace RT_NS {
+
+// ------------------------------------------------------------------ numerics
+#define DEV __device__ __forceinline__
+
+DEV float bits_f(uint32_t u) { return __uint_as_float(u); }
+DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
+
+#ifdef RT_FAST
+DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
+DEV float rt_pow(float x, float y)
+{
+    // v_log_f32 / v_exp_f32 are base 2; pow(0, y>0) = 0 falls out of log2(0) = -inf.
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+DEV float rt_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+#else
+DEV float rt_div(float a, float b) { return a / b; }
+DEV float rt_sqrt(float a) { return __builtin_sqrtf(a); }
+DEV float rt_rsq(float a) { return 1.0f / __builtin_sqrtf(a); }
+
+// pow(x, y) = exp2(y * log2 x) with the polynomial kernels the reference's CPU GL runs
+// (mantissa/exponent split + degree-4 minimax in ((m-1)/(m+1))^2; floor/fraction split +
+// degree-5 minimax), multiply-adds fused.
+DEV float lp_log2(float x)
+{
+    uint32_t i = f_bits(x);
+    float e = (float)((int)((i & 0x7f800000u) >> 23) - 127);
+    float m = bits_f((i & 0x007fffffu) | 0x3f800000u);
+    float y = (m - 1.0f) / (m + 1.0f);
+    float z = y * y;
+    float z2 = z * z;
+    float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f), 0x1.715476p+1f);
+    float odd = __builtin_fmaf(z2, 0x1.9d062cp-2f, 0x1.ec6ff2p-1f);
+    float p = __builtin_fmaf(odd, z, even);
+    float r = __builtin_fmaf(y, p, e);
+    if (x >= __builtin_inff()) r = __builtin_inff();
+    if (x == 0.0f) r = -__builtin_inff();
+    if (!(x >= 0.0f)) r = __builtin_nanf("");
+    return r;
+}
+DEV float rt_pow(float x, float y)
+{
+    if (!(x < 0.0f || x > 0.0f)) return 0.0f;
+    float t = lp_log2(x) * y;
+    if (t != t) return t;
+    t = (128.0f < t) ? 128.0f : t;
+    t = (-0x1.fbfffep+6f > t) ? -0x1.fbfffep+6f : t;
+    float fl = __builtin_floorf(t);
+    float fpart = t - fl;
+    int ipart = (int)fl;
+    float scale = bits_f((uint32_t)(ipart + 127) << 23);
+    float x2 = fpart * fpart;
+    float odd = __builtin_fmaf(x2, __builtin_fmaf(x2, 0x1.ec320ap-10f, 0x1.c95446p-5f), 0x1.62e4f6p-1f);
+    float even = __builtin_fmaf(x2, __builtin_fmaf(x2, 0x1.26900cp-7f, 0x1.ebd5a8p-3f), 1.0f);
+    float p = __builtin_fmaf(odd, fpart, even);
+    return scale * p;
+}
+// cos(x): octant reduction with a three-part pi/4 and the sin/cos minimax pair.
+DEV float rt_cos(float x)
+{
+    float xa = __builtin_fabsf(x);
+    float sy = xa * 0x1.45f306p+0f;
+    int j = (int)sy;
+    j = (j + 1) & ~1;
+    float yf = (float)j;
+    int emm2 = j - 2;
+    uint32_t sign_bit = ((uint32_t)(~emm2) & 4u) << 29;
+    bool use_sin = (emm2 & 2) == 0;
+    float r = __builtin_fmaf(yf, -0.78515625f, xa);
+    r = __builtin_fmaf(yf, -0x1.fb4p-13f, r);
+    r = __builtin_fmaf(yf, -0x1.4442d2p-25f, r);
+    float z = r * r;
+    float s = __builtin_fmaf(z, -0x1.9943f2p-13f, 0x1.11073cp-7f);
+    s = __builtin_fmaf(s, z, -0x1.555546p-3f);
+    s = s * z;
+    s = __builtin_fmaf(s, r, r);
+    float c = __builtin_fmaf(z, 0x1.99eb9cp-16f, -0x1.6c0c34p-10f);
+    c = __builtin_fmaf(c, z, 0x1.55554ap-5f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    float res = bits_f(f_bits(use_sin ? s : c) ^ sign_bit);
+    if ((f_bits(x) & 0x7f800000u) == 0x7f800000u) return __builtin_nanf("");
+    res = (res < 1.0f) ? res : 1.0f;
+    res = (res > -1.0f) ? res : -1.0f;
+    return res;
+}
+#endif
+
+// acos as the GLSL front end lowers it (both flavours; it is six cheap ops and a sqrt).
+DEV float rt_acos(float x)
+{
+    const float half_pi = 0x1.921fb6p+0f;
+    float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    float ax = __builtin_fabsf(x);
+    float t = rt_sqrt(1.0f - ax);
+    float p = ax * -0x1.8334bep-6f;
+    p = 0x1.4d1b0ep-4f + p;
+    p = ax * p;
+    p = -0x1.b78128p-3f + p;
+    p = ax * p;
+    p = half_pi + p;
+    float q = t * p;
+    q = half_pi - q;
+    q = s * q;
+    return half_pi - q;
+}
+
+DEV float sign_f(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+// max(0, x) with NaN -> 0, as the reference's max(0.0, x) behaves on its CPU GL
+DEV float max0(float x) { return x > 0.0f ? x : 0.0f; }
+// dot product in the reference's summation order: (z + y) + x
+DEV float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (az * bz + ay * by) + ax * bx;
+}
+
+// ------------------------------------------------------------------ event counters
+template <bool DEBUG> struct Counters {
+    unsigned int *lds_ev;
+    DEV void add(int) const {}
+};
+template <> struct Counters<true> {
+    unsigned int *lds_ev;
+    DEV void add(int ev) const { atomicAdd(&lds_ev[ev], 1u); }
+};
+#define CNT(ev) cnt.add(ev)
+
+// ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
+#define Q_EPS 1e-7f
+
+struct RootMin {
+    float t; bool found;
+    DEV void offer(float r) { if (r > 0.001f && r < t) { t = r; found = true; } }
+};
+
+// solve_quadratic (:159-180) for the monic calls of solve_quartic: a = 1.
+// bb is b*b as the compiled reference has it.  Offers (root - offset) to `rm`.
+template <bool DEBUG>
+DEV void quad_monic_offer(float bb, float b, float c, float offset, RootMin &rm, const Counters<DEBUG> &cnt)
+{
+    float disc = bb - 4.0f * c;
+    if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); return; }
+    CNT(EV_QUAD_FULL);
+    disc = max0(disc);
+    float sq = rt_sqrt(disc);
+    CNT(EV_ROOT_OUT);
+    rm.offer((-b + sq) * 0.5f - offset);
+    if (!(disc < Q_EPS)) { CNT(EV_ROOT_OUT); rm.offer((-b - sq) * 0.5f - offset); }
+}
+
+// Smallest root > 0.001 of t^4 + A t^3 + B t^2 + C t + D (Ferrari, :250-305 + :345-352).
+template <bool DEBUG>
+DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const Counters<DEBUG> &cnt)
+{
+    float a2 = a * a;
+    float p = b - 0.375f * a2;
+    float q = (c - (0.5f * a) * b) + (0.125f * a2) * a;
+    float r = ((d - (0.25f * a) * c) + (0.0625f * a2) * b) - (0.01171875f * a2) * a2;
+    float offset = 0.25f * a;
+    RootMin rm; rm.t = 1e20f; rm.found = false;
+    if (__builtin_fabsf(q) < Q_EPS) {
+        // biquadratic (:262-276): quadratic in y^2
+        float disc = p * p - 4.0f * r;
+        if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); }
+        else {
+            CNT(EV_QUAD_FULL);
+            disc = max0(disc);
+            float sq = rt_sqrt(disc);
+            int ny = disc < Q_EPS ? 1 : 2;
+            float z0 = (-p + sq) * 0.5f, z1 = (-p - sq) * 0.5f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float z = i == 0 ? z0 : z1;
+                if (i < ny && z >= -Q_EPS) {
+                    CNT(EV_BIQ_Z);
+                    float y = rt_sqrt(max0(z));
+                    CNT(EV_ROOT_OUT);
+                    rm.offer(y - offset);
+                    if (y > Q_EPS) { CNT(EV_ROOT_OUT); rm.offer(-y - offset); }
+                }
+            }
+        }
+    } else {
+        // resolvent cubic u^3 + 2p u^2 + (p^2 - 4r) u - q^2 (:281), first root only (:285)
+        CNT(EV_CUBIC);
+        float an = 2.0f * p;
+        float bn = p * p - 4.0f * r;
+        float cn = -(q * q);
+        float an2 = an * an;
+        float pc = bn - rt_div(an2, 3.0f);
+        float off_c = rt_div(an, 3.0f);
+        float qc = (cn - rt_div(an * bn, 3.0f)) + rt_div((2.0f * an2) * an, 27.0f);
+        float half_q = 0.5f * qc;
+        float p3 = (pc * pc) * pc;
+        float disc = half_q * half_q + rt_div(p3, 27.0f);
+        float u;
+        if (disc >= -Q_EPS) {
+            CNT(EV_CARDANO);
+            disc = max0(disc);
+            float sq = rt_sqrt(disc);
+            float A = -half_q + sq;
+            float B = -half_q - sq;
+            float rootA = sign_f(A) * rt_pow(__builtin_fabsf(A), 0x1.555556p-2f);
+            float rootB = sign_f(B) * rt_pow(__builtin_fabsf(B), 0x1.555556p-2f);
+            u = (rootA - off_c) + rootB;
+        } else {
+            CNT(EV_TRIG);
+            float rho = rt_sqrt(rt_div(-p3, 27.0f));
+            float x = rt_div(-half_q, rho);
+            x = (x > -1.0f) ? x : -1.0f;       // NaN -> -1
+            x = (x < 1.0f) ? x : 1.0f;
+            float theta = rt_div(rt_acos(x), 3.0f);
+            float m = 2.0f * rt_sqrt(rt_div(-pc, 3.0f));
+            u = m * rt_cos(theta) - off_c;
+        }
+        if (!(u < 0.0f)) {
+            CNT(EV_FERRARI_TAIL);
+            float w = rt_sqrt(u);
+            float term_A = 0.5f * (p + u);
+            float term_B = rt_div(0.5f * q, w + Q_EPS);
+            float bb = __builtin_fabsf(u);
+            quad_monic_offer<DEBUG>(bb, w, term_A - term_B, offset, rm, cnt);
+            quad_monic_offer<DEBUG>(bb, -w, term_A + term_B, offset, rm, cnt);
+        }
+    }
+    t_out = rm.t;
+    return rm.found;
+}
+
+struct TorusFrame { float ux, uy, uz, wx, wy, wz, vx, vy, vz, R, R2, r2, fourR2, eightR2; };
+
+DEV TorusFrame load_torus(const float *lds, int off_torus, int slot)
+{
+    const float4 *q = reinterpret_cast<const float4 *>(lds + off_torus + 16 * slot);
+    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    TorusFrame f;
+    f.ux = a.x; f.uy = a.y; f.uz = a.z; f.wx = a.w;
+    f.wy = b.x; f.wz = b.y; f.vx = b.z; f.vy = b.w;
+    f.vz = c.x; f.R = c.y; f.R2 = c.z; f.r2 = c.w;
+    f.fourR2 = d.x; f.eightR2 = d.y;
+    return f;
+}
+
+// Two Newton steps on the selected root; kept only if the residual shrinks.
+DEV float newton_polish(float A, float B, float C, float D, float t)
+{
+    float t0 = t;
+    float f0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t, 1.0f, A), t, B), t, C), t, D);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float f = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
+        float df = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(4.0f, t, 3.0f * A), t, 2.0f * B), t, C);
+        float step = f * __builtin_amdgcn_rcpf(df);
+        t = t - step;
+    }
+    float f1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
+    bool ok = __builtin_fabsf(f1) < __builtin_fabsf(f0) && t > 0.001f;
+    return ok ? t : t0;
+}
+
+// intersect_torus (:309-352) up to the root; ocx.. = ray origin - centre.
+template <bool DEBUG>
+DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, float dx, float dy, float dz,
+                       int polish, float &t_out, const Counters<DEBUG> &cnt)
+{
+    CNT(EV_TORUS_CALL);
+    float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
+    float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
+    float roz = dot3(ocx, ocy, ocz, f.vx, f.vy, f.vz);
+    float rdx = dot3(dx, dy, dz, f.ux, f.uy, f.uz);
+    float rdy = dot3(dx, dy, dz, f.wx, f.wy, f.wz);
+    float rdz = dot3(dx, dy, dz, f.vx, f.vy, f.vz);
+    float xx = rox * rdx, yy = roy * rdy, zz = roz * rdz;
+    float n = (zz + yy) + xx;
+    float sx = rox * rox, sy = roy * roy, sz = roz * roz;
+    float m = (sz + sy) + sx;
+    float rd_dxz = rdx * rdx + rdz * rdz;
+    float ro_rd_dxz = xx + zz;
+    float ro_dxz = sx + sz;
+    float k = (m + f.R2) - f.r2;
+    float four_n = 4.0f * n;
+    float A = four_n;
+    float B = (2.0f * k + four_n * n) - f.fourR2 * rd_dxz;
+    float C = four_n * k - f.eightR2 * ro_rd_dxz;
+    float D = k * k - f.fourR2 * ro_dxz;
+    float t;
+    bool found = quartic_nearest<DEBUG>(A, B, C, D, t, cnt);
+    if (found && polish) t = newton_polish(A, B, C, D, t);
+    t_out = t;
+    return found;
+}
+
+// ------------------------------------------------------------------ trace (fragment_shader.glsl:379-435)
+// Closest hit as (t, id): id -1 none, 0..n-1 scene object, n ground plane.
+template <bool DEBUG>
+DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
+                       float ox, float oy, float oz, float dx, float dy, float dz,
+                       float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+{
+    CNT(EV_TRACE);
+    float bt = 1e30f;
+    int bid = -1;
+    const float4 *bound = reinterpret_cast<const float4 *>(lds);
+    const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
+    const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
+    const int n = L.n;
+    for (int i = 0; i < n; ++i) {
+        float4 q = bound[i];                          // LDS broadcast: same address in every lane
+        float ocx = ox - q.x, ocy = oy - q.y, ocz = oz - q.z;
+        float b = dot3(ocx, ocy, ocz, dx, dy, dz);
+        float oc2 = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
+        float c = oc2 - q.w;
+        float disc = b * b - c;
+        if (DEBUG) { if (kind[i] >= 0) CNT(EV_BOUND_TORUS_RADIUS); }
+        if (disc < 0.0f) { CNT(EV_BOUND_CULL_DISC); continue; }
+        CNT(EV_BOUND_TBOUND);
+        float t_bound = -b - rt_sqrt(disc);
+        if (t_bound > bt) continue;
+        int kd = kind[i];
+        float t; bool hit;
+        if (kd < 0) {
+            // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
+            CNT(EV_SPHERE_CALL);
+            float b2 = 2.0f * b;
+            float ds = b2 * b2 - (4.0f * a) * c;
+            hit = false; t = 0.0f;
+            if (!(ds < 0.0f)) {
+                float sq = rt_sqrt(ds);
+                float two_a = 2.0f * a;
+                CNT(EV_SPHERE_ROOT);
+                t = rt_div(-b2 - sq, two_a);
+                if (t < 0.0f) { CNT(EV_SPHERE_ROOT); t = rt_div(-b2 + sq, two_a); }
+                hit = t > 0.001f;
+                if (hit) CNT(EV_SPHERE_HIT);
+            }
+        } else {
+            TorusFrame f = load_torus(lds, L.off_torus, kd);
+            hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
+            if (hit) CNT(EV_TORUS_HIT);
+        }
+        if (hit && t < bt) { bt = t; bid = i; }
+    }
+    // intersect_plane (:107-123): y = -1, two-sided
+    CNT(EV_PLANE_CALL);
+    bool ok = __builtin_fabsf(dy) > 0.0001f;
+    if (ok) {
+        CNT(EV_PLANE_T);
+        float t = rt_div(-1.0f - oy, dy);
+        if (t > 0.001f) {
+            CNT(EV_PLANE_HIT);
+            if (t < bt) { bt = t; bid = n; }
+        }
+    }
+    best_t = bt; best_id = bid;
+}
+
+// ------------------------------------------------------------------ pending-ray slots
+template <int CAP> struct Pending {
+    float ox[CAP], oy[CAP], oz[CAP], dx[CAP], dy[CAP], dz[CAP], tx[CAP], ty[CAP], tz[CAP], ior[CAP];
+    int depth[CAP];
+};
+
+#define SEL_STORE(arr, val) arr[k] = (k == slot) ? (val) : arr[k]
+#define SEL_LOAD(dst, arr) dst = (k == slot) ? arr[k] : dst
+
+// ------------------------------------------------------------------ the kernel
+enum { ST_PATH = 0, ST_SHADOW = 1 };
+
+template <int CAP, bool DEBUG>
+__global__ __launch_bounds__(256)
+void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
+               unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
+{
+    extern __shared__ float4 lds4[];
+    float *lds = reinterpret_cast<float *>(lds4);
+    const SceneLayout L = kp.scene;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(scene);
+        const int nq = L.total_dwords >> 2;
+        for (int i = threadIdx.x; i < nq; i += 256) lds4[i] = src[i];
+    }
+    Counters<DEBUG> cnt;
+    cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + L.total_dwords);
+    if (DEBUG) { if (threadIdx.x < EV_COUNT) cnt.lds_ev[threadIdx.x] = 0u; }
+    __syncthreads();
+
+    // ---- which pixel
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int band = kp.part + blockIdx.y * kp.nparts;
+    const int in_band = (wave >> 1) * 8 + (lane >> 3);
+    const int row = band * 16 + in_band;                 // output row
+    const int packed_row = blockIdx.y * 16 + in_band;    // row inside this part's buffer
+    bool active = px < kp.w && row < kp.h;
+    const int gy = kp.bottom_up ? row : (kp.h - 1 - row); // GL row (0 = bottom)
+
+    const int N = kp.spp;
+    const int nsamples = N * N;
+    const float inv_spp = 1.0f / (float)nsamples;
+
+    // ---- per-lane state
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 1, dz = 0;  // ray being traced
+    float thx = 1, thy = 1, thz = 1, cur_ior = 1;          // path segment: throughput, medium
+    int depth = 0;
+    float fr = 0, fg = 0, fb = 0;                          // colour of the current sample
+    float accr = 0, accg = 0, accb = 0;                    // sum over samples
+    int sample = 0;
+    int np = 0;                                            // pending refraction rays
+    Pending<CAP> pend;
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        pend.ox[k] = pend.oy[k] = pend.oz[k] = 0; pend.dx[k] = pend.dy[k] = pend.dz[k] = 0;
+        pend.tx[k] = pend.ty[k] = pend.tz[k] = 0; pend.ior[k] = 1; pend.depth[k] = 0;
+    }
+    int state = ST_PATH;
+    // shading context carried across the shadow hops of one hit
+    float hx = 0, hy = 0, hz = 0;            // hit position
+    float nx = 0, ny = 1, nz = 0;            // geometric normal
+    float pdx = 0, pdy = 0, pdz = 0;         // direction of the path ray that hit
+    float mr = 0, mg = 0, mb = 0, m_refl = 0, m_transp = 0;
+    float osign = 1, dni = 0, eta = 1, n2 = 1, F = 0, local = 0;
+    float light_dist = 0, travelled = 0, filr = 1, filg = 1, filb = 1;
+    float stx = 0, sty = 0, stz = 0;         // shadow step = L * 0.001
+    int hop = 0;
+    // debug capture
+    int seg = 0, cap_nseg = 0; float cap_id = -2.0f, cap_t = 0.0f, cap_depth = 0.0f;
+
+    auto start_sample = [&](int s) {
+        // main() (:650-668): pixel centre + stratified offset
+        int si = s % N, sj = s / N;
+        float offx = (float)(((double)si + 0.5) / (double)N - 0.5);
+        float offy = (float)(((double)sj + 0.5) / (double)N - 0.5);
+        float fx = ((float)px + 0.5f) + offx;
+        float fy = ((float)gy + 0.5f) + offy;
+        float uvx = rt_div(fx * 2.0f - kp.res_w, kp.res_h);
+        float uvy = rt_div(fy * 2.0f - kp.res_h, kp.res_h);
+        float rx = (uvx * kp.right[0] + uvy * kp.up[0]) + kp.focal * kp.fwd[0];
+        float ry = (uvx * kp.right[1] + uvy * kp.up[1]) + kp.focal * kp.fwd[1];
+        float rz = (uvx * kp.right[2] + uvy * kp.up[2]) + kp.focal * kp.fwd[2];
+        float rs = rt_rsq(dot3(rx, ry, rz, rx, ry, rz));
+        dx = rx * rs; dy = ry * rs; dz = rz * rs;
+        ox = kp.eye[0]; oy = kp.eye[1]; oz = kp.eye[2];
+        thx = thy = thz = 1.0f; cur_ior = 1.0f; depth = 0;
+        fr = fg = fb = 0.0f; np = 0; state = ST_PATH; seg = 0;
+        CNT(EV_PIXEL_PATH);
+    };
+    if (active) start_sample(0);
+
+    while (active) {
+        float t; int id;
+        trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
+
+        bool spawn = false;     // this lane finished shading a hit: spawn children
+        bool pop = false;       // this lane needs its next ray from the pending slots
+
+        if (state == ST_PATH) {
+            if (DEBUG) {
+                if (sample == 0 && seg == kp.capture_seg) { cap_id = (float)id; cap_t = id >= 0 ? t : 0.0f; cap_depth = (float)depth; }
+                seg++;
+            }
+            if (id < 0) {
+                // sky (:570-580); mix(h, z, t) = h + t*(z - h); the blue channel is exactly 1
+                CNT(EV_SEG_MISS);
+                float tt = 0.5f + 0.5f * dy;
+                float sx = 0.8f + tt * (0.5f - 0.8f);
+                float sy = 0.9f + tt * (0.7f - 0.9f);
+                fr = fr + sx * thx;
+                fg = fg + sy * thy;
+                fb = fb + thz;
+                pop = true;
+            } else {
+                CNT(EV_SEG_HIT);
+                // ---- HitInfo of the winner (:93-100, :122-141, :357-372)
+                hx = ox + t * dx; hy = oy + t * dy; hz = oz + t * dz;
+                float h_ior;
+                if (id == L.n) {
+                    nx = 0.0f; ny = 1.0f; nz = 0.0f;
+                    float s = __builtin_floorf(hx) + __builtin_floorf(hz);
+                    float two_fl = 2.0f * __builtin_floorf(s * 0.5f);
+                    float col = (s == two_fl) ? 0.9f : 0.1f;
+                    mr = mg = mb = col; m_refl = 0.05f; m_transp = 0.0f; h_ior = 1.0f;
+                } else {
+                    const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
+                    float4 m0 = mat[0], m1 = mat[1];
+                    mr = m0.x; mg = m0.y; mb = m0.z; m_refl = m0.w; m_transp = m1.x; h_ior = m1.y;
+                    float4 q = reinterpret_cast<const float4 *>(lds)[id];
+                    int kd = reinterpret_cast<const int *>(lds + L.off_kind)[id];
+                    if (kd < 0) {
+                        float vx = hx - q.x, vy = hy - q.y, vz = hz - q.z;
+                        float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
+                        nx = vx * rs; ny = vy * rs; nz = vz * rs;
+                    } else {
+                        TorusFrame f = load_torus(lds, L.off_torus, kd);
+                        float ocx = ox - q.x, ocy = oy - q.y, ocz = oz - q.z;
+                        float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
+                        float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
+                        float roz = dot3(ocx, ocy, ocz, f.vx, f.vy, f.vz);
+                        float rdx = dot3(dx, dy, dz, f.ux, f.uy, f.uz);
+                        float rdy = dot3(dx, dy, dz, f.wx, f.wy, f.wz);
+                        float rdz = dot3(dx, dy, dz, f.vx, f.vy, f.vz);
+                        float lx = rox + t * rdx, ly = roy + t * rdy, lz = roz + t * rdz;
+                        float alpha = rt_div(f.R, rt_sqrt(lx * lx + lz * lz));
+                        float g = 1.0f - alpha;
+                        float ax = lx * g, ay = ly, az = lz * g;
+                        float rs = rt_rsq(dot3(ax, ay, az, ax, ay, az));
+                        ax = ax * rs; ay = ay * rs; az = az * rs;
+                        float wx = (ax * f.ux + ay * f.wx) + az * f.vx;
+                        float wy = (ax * f.uy + ay * f.wy) + az * f.vy;
+                        float wz = (ax * f.uz + ay * f.wz) + az * f.vz;
+                        float rs2 = rt_rsq(dot3(wx, wy, wz, wx, wy, wz));
+                        nx = wx * rs2; ny = wy * rs2; nz = wz * rs2;
+                    }
+                }
+                // ---- orientation + Fresnel (:583-597, :524-534); dot(d,n) < 0 in compiled form
+                bool entering = (dz * nz + dy * ny) < -(dx * nx);
+                osign = entering ? 1.0f : -1.0f;
+                float n1 = entering ? cur_ior : h_ior;
+                n2 = entering ? h_ior : 1.0f;
+                float onx = entering ? nx : -nx, ony = entering ? ny : -ny, onz = entering ? nz : -nz;
+                dni = dot3(dx, dy, dz, onx, ony, onz);
+                float cos_t = __builtin_fabsf(dni);
+                float r0 = rt_div(n1 - n2, n1 + n2); r0 = r0 * r0;
+                eta = rt_div(n1, n2);
+                float sin_t2 = (eta * eta) * (1.0f - cos_t * cos_t);
+                if (sin_t2 > 1.0f) { CNT(EV_FRESNEL_TIR); F = 1.0f; }
+                else { CNT(EV_FRESNEL_FULL); F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_t, 5.0f); }
+                local = (1.0f - m_refl) - m_transp;
+                pdx = dx; pdy = dy; pdz = dz;
+                if (local > 0.0f) {
+                    // phong_lighting -> calculate_light_attenuation set-up (:443-450)
+                    CNT(EV_LOCAL); CNT(EV_ATTEN_FIXED);
+                    float lx = kp.light[0] - hx, ly = kp.light[1] - hy, lz = kp.light[2] - hz;
+                    float d2 = dot3(lx, ly, lz, lx, ly, lz);
+                    light_dist = rt_sqrt(d2);
+                    float rs = rt_rsq(d2);
+                    dx = lx * rs; dy = ly * rs; dz = lz * rs;      // shadow direction L
+                    stx = dx * 0.001f; sty = dy * 0.001f; stz = dz * 0.001f;
+                    ox = hx + stx; oy = hy + sty; oz = hz + stz;
+                    filr = filg = filb = 1.0f; travelled = 0.0f; hop = 0;
+                    if (kp.hops > 0) state = ST_SHADOW;             // trace the first hop next
+                    else spawn = true;                               // zero hops: unattenuated
+                } else {
+                    spawn = true;
+                }
+            }
+        } else {
+            // ---- one shadow hop came back (:453-480)
+            bool lit_done = true;       // attenuation finished -> shade now
+            if (id >= 0) {
+                CNT(EV_HOP_HIT_TEST);
+                float reach = t + travelled;
+                if (reach < light_dist) {
+                    CNT(EV_HOP_FILTER);
+                    float cr, cg, cb, ctr;
+                    if (id == L.n) {
+                        // the ground is opaque (:128): whichever checker colour, colour * 0 = +0
+                        cr = cg = cb = 0.9f; ctr = 0.0f;
+                    } else {
+                        const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
+                        float4 m0 = mat[0];
+                        cr = m0.x; cg = m0.y; cb = m0.z; ctr = mat[1].x;
+                    }
+                    filr = filr * (cr * ctr); filg = filg * (cg * ctr); filb = filb * (cb * ctr);
+                    if ((filb * filb + filg * filg) == -(filr * filr)) {
+                        filr = filg = filb = 0.0f;               // fully blocked (:468-470)
+                    } else {
+                        CNT(EV_HOP_CONTINUE);
+                        travelled = reach;
+                        hop++;
+                        if (hop < kp.hops) {
+                            ox = (ox + t * dx) + stx; oy = (oy + t * dy) + sty; oz = (oz + t * dz) + stz;
+                            lit_done = false;                    // keep tracing towards the light
+                        }
+                    }
+                }
+            }
+            if (lit_done) { spawn = true; state = ST_PATH; }
+        }
+
+        if (spawn) {
+            if (local > 0.0f) {
+                // phong_lighting (:488-514) with attenuation = fil*, light direction = d (still L)
+                float ambr = 0.05f * mr, ambg = 0.05f * mg, ambb = 0.05f * mb;
+                float lcr = ambr, lcg = ambg, lcb = ambb;
+                if ((filb * filb + filg * filg) != -(filr * filr)) {
+                    CNT(EV_PHONG_FULL);
+                    float Lx = dx, Ly = dy, Lz = dz;
+                    float nlz = nz * Lz, nly = ny * Ly, nlx = nx * Lx;
+                    float diff = max0((nlz + nly) + nlx);
+                    float vx = kp.eye[0] - hx, vy = kp.eye[1] - hy, vz = kp.eye[2] - hz;
+                    float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
+                    vx = vx * rs; vy = vy * rs; vz = vz * rs;
+                    float two_dn = (((-nlz) + (-nly)) + (-nlx)) * 2.0f;
+                    float rx = -Lx - two_dn * nx, ry = -Ly - two_dn * ny, rz = -Lz - two_dn * nz;
+                    float sd = max0(dot3(vx, vy, vz, rx, ry, rz));
+                    float spec = 0.5f * rt_pow(sd, 32.0f);
+                    lcr = ambr + (diff * mr + spec) * filr;
+                    lcg = ambg + (diff * mg + spec) * filg;
+                    lcb = ambb + (diff * mb + spec) * filb;
+                } else {
+                    CNT(EV_PHONG_SHADOWED);
+                }
+                fr = fr + (lcr * local) * thx;
+                fg = fg + (lcg * local) * thy;
+                fb = fb + (lcb * local) * thz;
+            }
+            // ---- children (:606-643)
+            pop = true;
+            if (depth < kp.max_depth - 1) {
+                float onx = osign * nx, ony = osign * ny, onz = osign * nz;
+                if (m_transp > 0.0f) {
+                    CNT(EV_REFR_TRY);
+                    float k2 = 1.0f - eta * (eta * (1.0f - dni * dni));
+                    float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+                    if (!(k2 < 0.0f)) {
+                        float g = eta * dni + rt_sqrt(k2);
+                        rx = eta * pdx - g * onx; ry = eta * pdy - g * ony; rz = eta * pdz - g * onz;
+                    }
+                    bool valid = -(rz * rz + ry * ry) < rx * rx;
+                    if (valid && np < kp.stack_size) {
+                        CNT(EV_REFR_PUSH);
+                        float omf = 1.0f - F;
+                        float qx = hx + rx * 0.001f, qy = hy + ry * 0.001f, qz = hz + rz * 0.001f;
+                        float ux = ((thx * omf) * m_transp) * mr;
+                        float uy = ((thy * omf) * m_transp) * mg;
+                        float uz = ((thz * omf) * m_transp) * mb;
+                        const int slot = np;
+#pragma unroll
+                        for (int k = 0; k < CAP; ++k) {
+                            SEL_STORE(pend.ox, qx); SEL_STORE(pend.oy, qy); SEL_STORE(pend.oz, qz);
+                            SEL_STORE(pend.dx, rx); SEL_STORE(pend.dy, ry); SEL_STORE(pend.dz, rz);
+                            SEL_STORE(pend.tx, ux); SEL_STORE(pend.ty, uy); SEL_STORE(pend.tz, uz);
+                            SEL_STORE(pend.ior, n2); SEL_STORE(pend.depth, depth + 1);
+                        }
+                        np++;
+                    } else if (valid) CNT(EV_DROP);
+                }
+                CNT(EV_REFL_EVAL);
+                float Rt = m_refl + (1.0f - m_refl) * F;
+                if (Rt > 0.0f) {
+                    if (np < kp.stack_size) {
+                        // the reflection ray is the next one visited: continue with it directly
+                        CNT(EV_REFL_PUSH);
+                        float two_dni = dni * 2.0f;
+                        ox = hx + onx * 0.001f; oy = hy + ony * 0.001f; oz = hz + onz * 0.001f;
+                        dx = pdx - two_dni * onx; dy = pdy - two_dni * ony; dz = pdz - two_dni * onz;
+                        thx = thx * Rt; thy = thy * Rt; thz = thz * Rt;
+                        depth = depth + 1;                       // medium (cur_ior) unchanged (:639)
+                        pop = false;
+                    } else CNT(EV_DROP);
+                }
+            }
+        }
+
+        if (pop) {
+            if (np > 0) {
+                np--;
+                const int slot = np;
+#pragma unroll
+                for (int k = 0; k < CAP; ++k) {
+                    SEL_LOAD(ox, pend.ox); SEL_LOAD(oy, pend.oy); SEL_LOAD(oz, pend.oz);
+                    SEL_LOAD(dx, pend.dx); SEL_LOAD(dy, pend.dy); SEL_LOAD(dz, pend.dz);
+                    SEL_LOAD(thx, pend.tx); SEL_LOAD(thy, pend.ty); SEL_LOAD(thz, pend.tz);
+                    SEL_LOAD(cur_ior, pend.ior); SEL_LOAD(depth, pend.depth);
+                }
+            } else {
+                // path finished: next stratified sample of this pixel, or done
+                if (nsamples == 1) { accr = fr; accg = fg; accb = fb; }
+                else { accr = accr + fr; accg = accg + fg; accb = accb + fb; }
+                if (DEBUG && sample == 0) cap_nseg = seg;
+                sample++;
+                if (sample < nsamples) start_sample(sample);
+                else active = false;
+            }
+        }
+    }
+
+    // ---- framebuffer write (:674 + RGBA8 UNORM conversion: clamp, *255, round to even)
+    const bool in_frame = px < kp.w && row < kp.h;
+    if (!DEBUG) {
+        if (in_frame) {
+            if (nsamples > 1) { accr = accr * inv_spp; accg = accg * inv_spp; accb = accb * inv_spp; }
+            size_t o = (size_t)packed_row * kp.w + px;
+            if (kp.out_f32) {
+                reinterpret_cast<float4 *>(out)[o] = make_float4(accr, accg, accb, 1.0f);
+            } else {
+                auto u8 = [](float c) -> uint32_t {
+                    float s = !(c > 0.0f) ? 0.0f : (c >= 1.0f ? 1.0f : c);
+                    return (uint32_t)__builtin_rintf(s * 255.0f);
+                };
+                uint32_t v = u8(accr) | (u8(accg) << 8) | (u8(accb) << 16) | 0xff000000u;
+                reinterpret_cast<uint32_t *>(out)[o] = v;
+            }
+        }
+    } else {
+        if (in_frame && cap_out) {
+            size_t o = ((size_t)packed_row * kp.w + px) * 4;
+            cap_out[o] = cap_id; cap_out[o + 1] = cap_t; cap_out[o + 2] = cap_depth; cap_out[o + 3] = (float)cap_nseg;
+        }
+        __syncthreads();
+        if (ev_out && threadIdx.x < EV_COUNT) atomicAdd(&ev_out[threadIdx.x], (unsigned long long)cnt.lds_ev[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+template <int CAP, bool DEBUG>
+static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
+                          float *d_cap, hipStream_t stream, LaunchInfo *info)
+{
+    auto kfn = rt_kernel<CAP, DEBUG>;
+    size_t lds = (size_t)kp.scene.total_dwords * 4 + (DEBUG ? EV_COUNT * 4 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int bands = (kp.h + 15) / 16;
+    int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;
+    if (my_bands <= 0 || kp.w <= 0) return 0;
+    dim3 grid((kp.w + 15) / 16, my_bands);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, kp, d_scene, d_out, d_ev, d_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (info) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn)) == hipSuccess) info->vgprs = fa.numRegs;
+        info->lds_bytes = (int)lds;
+        info->pending_cap = CAP;
+    }
+    return 0;
+}
+
+static int needed_cap(const KParams &kp)
+{
+    int need = kp.stack_size < kp.max_depth - 1 ? kp.stack_size : kp.max_depth - 1;
+    return need < 1 ? 1 : need;
+}
+
+int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream, LaunchInfo *info)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int need = needed_cap(kp);
+    if (need <= 4) return launch_variant<4, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+    if (need <= 8) return launch_variant<8, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+    return launch_variant<16, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+}
+
+int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events, float *d_capture,
+                 void *stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return launch_variant<16, true>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
+}
+
+}  // namespace RT_NS

@@ -1,0 +1,74 @@
+// Internal types shared by the host API (rt_api.hip) and the device code (rt_device.hip).
+#pragma once
+#include <stdint.h>
+
+// ---- staged scene ("blob"): what the host packs, what every workgroup copies to LDS ----
+//
+// Layout in dwords, all sections 16-byte aligned:
+//   [0, 4n)              bound[i]    = { cx, cy, cz, bounding_radius^2 }
+//   [4n, 4n + 8n)        material[i] = { r, g, b, reflectivity } { transparency, ior, 0, 0 }
+//   [12n, 12n + 16*nt)   torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
+//   [.., + n)            kind[i]     = -1 for a sphere, torus slot s >= 0 for a torus
+// Keeping only the 16-byte bound record in the per-object hot loop and everything else
+// behind the bound test is what makes 1024 objects fit in LDS next to several workgroups.
+struct SceneLayout {
+    int n, ntori;
+    int off_material;   // dword offsets
+    int off_torus;
+    int off_kind;
+    int total_dwords;   // padded to a multiple of 4
+};
+
+static inline SceneLayout scene_layout(int n, int ntori)
+{
+    SceneLayout L;
+    L.n = n; L.ntori = ntori;
+    L.off_material = 4 * n;
+    L.off_torus = 12 * n;
+    L.off_kind = 12 * n + 16 * ntori;
+    L.total_dwords = (L.off_kind + n + 3) & ~3;
+    return L;
+}
+
+// ---- kernel arguments (passed by value: lands in the kernarg segment / SGPRs) ----
+struct KParams {
+    float right[3], up[3], fwd[3], eye[3];   // columns of u_camera_to_world (fragment_shader.glsl:656-659)
+    float focal;
+    float light[3];
+    float res_w, res_h;
+    int w, h;
+    int max_depth, stack_size, hops, spp;
+    int bottom_up;          // output row order
+    int part, nparts;       // band split
+    int out_f32;            // 0: RGBA8, 1: float4
+    int polish;             // Newton polish on torus roots
+    int capture_seg;        // debug flavour only
+    SceneLayout scene;
+};
+
+// ---- work events (same classes, same weights as the shader-source FLOP convention) ----
+enum RtEvent {
+    EV_PIXEL_PATH, EV_TRACE, EV_BOUND_CULL_DISC, EV_BOUND_TBOUND, EV_BOUND_TORUS_RADIUS,
+    EV_SPHERE_CALL, EV_SPHERE_ROOT, EV_SPHERE_HIT,
+    EV_PLANE_CALL, EV_PLANE_T, EV_PLANE_HIT,
+    EV_TORUS_CALL, EV_QUAD_FULL, EV_QUAD_EARLY, EV_BIQ_Z, EV_ROOT_OUT,
+    EV_CUBIC, EV_CARDANO, EV_TRIG, EV_FERRARI_TAIL, EV_TORUS_HIT,
+    EV_SEG_MISS, EV_SEG_HIT, EV_FRESNEL_TIR, EV_FRESNEL_FULL, EV_LOCAL,
+    EV_PHONG_SHADOWED, EV_PHONG_FULL, EV_ATTEN_FIXED, EV_HOP_HIT_TEST, EV_HOP_FILTER, EV_HOP_CONTINUE,
+    EV_REFR_TRY, EV_REFR_PUSH, EV_REFL_EVAL, EV_REFL_PUSH, EV_DROP,
+    EV_COUNT
+};
+
+// Launchers, one set per numerics flavour (rt_device.hip is compiled twice).
+struct LaunchInfo { int vgprs; int lds_bytes; int pending_cap; };
+
+#define RT_DECLARE_FLAVOUR(NS)                                                                   \
+    namespace NS {                                                                               \
+    int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream,       \
+                      LaunchInfo *info);                                                         \
+    int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events,     \
+                     float *d_capture, void *stream);                                            \
+    }
+
+RT_DECLARE_FLAVOUR(rt_strict)
+RT_DECLARE_FLAVOUR(rt_fast)

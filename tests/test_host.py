@@ -1,0 +1,127 @@
+"""Host logic and the C-ABI surface, no GPU needed: camera matrix, camera controller,
+scene packing, library exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_camera_matrix_known_answer(rt):
+    """float32 camera_to_world of the reference's default camera (main.py:103-109, :253-274)."""
+    m = rt.default_camera().matrix()
+    expect = np.array([[0.70710677, -0.14701578, -0.6916548, 4.0],
+                       [0.0, 0.9781476, -0.20791169, 1.2],
+                       [-0.70710677, -0.14701578, -0.6916548, 3.0],
+                       [0.0, 0.0, 0.0, 1.0]], dtype=np.float32)
+    assert m.dtype == np.float32
+    assert np.array_equal(m, expect)
+
+
+def test_camera_basis_is_orthonormal(rt):
+    for yaw, pitch in [(-135, -12), (10, 45), (200, -89), (0, 0), (90, 89)]:
+        m = rt.camera_to_world((1, 2, 3), yaw, pitch).astype(np.float64)
+        b = m[:3, :3]
+        assert np.allclose(b.T @ b, np.eye(3), atol=1e-6)
+        assert np.allclose(m[:3, 3], [1, 2, 3])
+
+
+def test_controller_mouse_and_scroll(rt):
+    c = rt.CameraController()
+    c.cursor_pos(400, 400)              # first event only latches the position (main.py:424-426)
+    assert (c.camera.yaw, c.camera.pitch) == (-135.0, -12.0)
+    c.cursor_pos(410, 380)              # +10 px right, 20 px up, sensitivity 0.1
+    assert c.camera.yaw == pytest.approx(-134.0)
+    assert c.camera.pitch == pytest.approx(-10.0)
+    c.cursor_pos(410, -5000)            # pitch clamps at +89 (main.py:438)
+    assert c.camera.pitch == 89.0
+    c.key_escape()                      # released mouse ignores motion (main.py:419-420)
+    c.cursor_pos(0, 0)
+    assert c.camera.pitch == 89.0
+    c.mouse_button()                    # click re-captures and re-latches (main.py:395-396, :345)
+    assert c.mouse_captured and c.first_mouse
+    c.scroll(100)
+    assert c.camera.focal_length == 10.0
+    c.scroll(-100)
+    assert c.camera.focal_length == 0.5
+    c.scroll(1)
+    assert c.camera.focal_length == pytest.approx(0.7)
+
+
+def test_controller_movement(rt):
+    c = rt.CameraController()
+    e0 = np.array(c.camera.eye)
+    c.process_keys({"W"}, 0.5)          # 3.0 units/s along the horizontal forward (main.py:322-327)
+    e1 = np.array(c.camera.eye)
+    assert e1[1] == pytest.approx(e0[1])
+    assert np.linalg.norm(e1 - e0) == pytest.approx(1.5, rel=1e-5)
+    c.process_keys({"SPACE"}, 1.0)
+    assert c.camera.eye[1] == pytest.approx(e1[1] + 3.0)
+    c.process_keys({"W"}, 1.0, focused=False)   # unfocused window: no movement (main.py:308-309)
+    assert np.allclose(c.camera.eye, [e1[0], e1[1] + 3.0, e1[2]])
+    c.process_keys({"A", "D"}, 1.0)             # opposite keys cancel
+    assert np.allclose(c.camera.eye, [e1[0], e1[1] + 3.0, e1[2]], atol=1e-6)
+
+
+def test_pack_scene_layout(rt):
+    arr = rt.api.pack_scene(rt.default_scene())
+    assert ctypes.sizeof(arr[0]) == 64
+    raw = np.frombuffer(bytes(arr), dtype=np.float32).reshape(5, 16)
+    assert raw[0, 4] == 1.0 and raw[0, 5:10].tolist() == [0, 0, 0, 0, 0]      # sphere: torus fields stay 0
+    assert raw[4, 4] == 0.0 and raw[4, 5:10].tolist() == [0, 1, 0, np.float32(0.8), np.float32(0.2)]
+    assert np.frombuffer(bytes(arr), dtype=np.int32).reshape(5, 16)[:, 0].tolist() == [1, 1, 1, 1, 2]
+
+
+def test_pack_scene_rejects_bad_input(rt):
+    s = rt.default_scene()
+    del s[1]["radius"]
+    with pytest.raises(rt.RtError):
+        rt.api.pack_scene(s)
+    s = rt.default_scene()
+    s[0]["colour"] = [1, 1, 1]
+    with pytest.raises(rt.RtError):
+        rt.api.pack_scene(s)
+    with pytest.raises(rt.RtError):
+        rt.api.pack_scene(rt.mixed_scene(1025))
+
+
+def test_scene_generators_are_deterministic(rt):
+    assert rt.tori_stress_scene() == rt.tori_stress_scene()
+    assert len(rt.tori_stress_scene()) == 64 and all(o["type"] == 2 for o in rt.tori_stress_scene())
+    s = rt.spheres_deep_scene()
+    assert len(s) == 256 and sum(o["transparency"] > 0 for o in s) == 128
+    m = rt.mixed_scene()
+    assert len(m) == 1024 and sum(o["type"] == 2 for o in m) == 256
+
+
+def test_library_exports_every_declared_symbol(rt):
+    """librt355.so loads without a GPU and exports exactly what include/rt355.h declares."""
+    header = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    declared = sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(rt.api.EXPORTS)
+    lib = rt.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rt_event_count() == 37
+    assert lib.rt_event_flops(0) == 30
+
+
+def test_struct_sizes_match_header(rt):
+    assert ctypes.sizeof(rt.api.RtObject) == 64
+    assert ctypes.sizeof(rt.api.RtParams) == 16 * 4 + 4 + 12 + 4 * 6 + 4 + 8
+    assert ctypes.sizeof(rt.api.RtTiming) == 20
+
+
+def test_calls_fail_cleanly_without_init(rt):
+    """Before rt_init every compute entry point reports RT_E_STATE instead of crashing."""
+    lib = rt.load_library()
+    if rt.api._inited_device is not None:
+        pytest.skip("library already bound to a GPU in this process")
+    p = rt.api.make_params(rt.default_camera(), 8, 8)
+    out = np.zeros((8, 8, 4), dtype=np.uint8)
+    assert lib.rt_render_device(ctypes.addressof(p), out.ctypes.data, out.nbytes, None, 0) == -4
+    assert b"rt_init" in lib.rt_last_error()
+    assert lib.rt_output_bytes(ctypes.addressof(p)) == 8 * 8 * 4

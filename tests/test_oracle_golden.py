@@ -1,0 +1,139 @@
+"""The CPU restatement (oracle/rt_oracle.c) against the golden vectors produced by the
+reference shader on Mesa llvmpipe (oracle/make_golden.py).  Bit-exact everywhere: RGBA8
+frames, float32 colours, per-segment hit ids, primary t, solver known answers."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import camera_for, golden_names, load_golden, scene_for
+
+FRAME_CASES = [n for n in golden_names() if not n.startswith("spp")]
+SMALL = [n for n in FRAME_CASES if "4k" not in n]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", FRAME_CASES)
+def test_frame_bit_exact(orc, name):
+    meta, arr = load_golden(name)
+    cam = camera_for(meta)
+    out = orc.render(scene_for(name), cam.matrix(), cam.focal_length, meta["w"], meta["h"], light=cam.light_pos,
+                     max_depth=meta["max_depth"], stack_size=meta["stack_size"], shadow_hops=meta["shadow_hops"],
+                     want_f32=True)
+    assert sha(out["rgba8"]) == meta["sha256_rgba8"]
+    assert sha(out["f32"]) == meta["sha256_rgba32f"]
+    for pr in meta["probes"]:
+        assert out["rgba8"][pr["y"], pr["x"]].tolist() == pr["rgba8"]
+        assert out["f32"][pr["y"], pr["x"]].view(np.uint32).tolist() == pr["rgba32f_bits"]
+    if "rgba8" in arr:
+        assert np.array_equal(out["rgba8"], arr["rgba8"])
+    if "rgb8" in arr:
+        assert np.array_equal(out["rgba8"][..., :3], arr["rgb8"])
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL if n != "quartic_kats"])
+def test_segment_masks_bit_exact(orc, name):
+    """Hit/miss masks: object id of every traced segment (visit order), primary t, segment count."""
+    meta, arr = load_golden(name)
+    if "seg0_id" not in arr:
+        pytest.skip("no segment captures stored")
+    cam = camera_for(meta)
+    scene = scene_for(name)
+    for k in range(6):
+        c = orc.capture(scene, cam.matrix(), cam.focal_length, meta["w"], meta["h"], k, light=cam.light_pos,
+                        max_depth=meta["max_depth"], stack_size=meta["stack_size"], shadow_hops=meta["shadow_hops"])
+        assert np.array_equal(c[..., 0].astype(np.int16), arr[f"seg{k}_id"]), f"segment {k} ids"
+        if k == 0:
+            assert np.array_equal(c[..., 1].view(np.uint32), arr["seg0_t"].view(np.uint32))
+            assert np.array_equal(c[..., 3].astype(np.int16), arr["nseg"])
+
+
+def test_default_800_known_answers(orc, rt):
+    """Primary-hit census and pixel values of the reference frame as shipped (800x800)."""
+    meta, arr = load_golden("default_800")
+    assert meta["sha256_rgba8"] == "90a725b78f4f4d3e9504e217544613a5b93cf9253d512c1b2994be217ee70f13"
+    ids = arr["seg0_id"]
+    census = {i: int((ids == i).sum()) for i in range(-1, 6)}
+    assert census == {-1: 178059, 0: 68666, 1: 4343, 2: 10886, 3: 10287, 4: 11721, 5: 356038}
+    rgb = arr["rgb8"]
+    assert rgb[0, 0].tolist() == [212, 215, 219]
+    assert rgb[400, 400].tolist() == [202, 220, 246]
+    assert rgb[560, 560].tolist() == [91, 89, 81]
+    assert rgb[380, 600].tolist() == [43, 47, 175]
+    assert rgb[700, 100].tolist() == [160, 200, 255]
+
+
+def test_4k_headline_sha():
+    meta, _ = load_golden("default_4k_d4s3")
+    assert meta["sha256_rgba8"] == "7d0f1e79eeb2aa9f319f19bdb447e606ed1c37dd0173150aa39417e4a87c6485"
+
+
+@pytest.mark.parametrize("name,N", [("spp2_200", 2), ("spp4_200", 4)])
+def test_stratified_samples(orc, rt, name, N):
+    meta, arr = load_golden(name)
+    cam = camera_for(meta)
+    out = orc.render(rt.default_scene(), cam.matrix(), cam.focal_length, meta["w"], meta["h"], spp_grid=N, want_f32=True)
+    assert np.array_equal(out["f32"][..., :3].view(np.uint32), arr["rgb32f"].view(np.uint32))
+
+
+def test_quartic_known_answers(orc):
+    import os
+    from conftest import GOLDEN
+    k = np.load(os.path.join(GOLDEN, "quartic_kats.npz"))
+    coefs, ref = k["coefs"], k["n_t_r0_r1"]
+    assert len(coefs) == 1024
+    for c, o in zip(coefs, ref):
+        r = orc.solve_quartic(*[float(v) for v in c])
+        t = np.float32(1e20)
+        for v in r:
+            if v > np.float32(0.001) and v < t:
+                t = v
+        mine = np.array([len(r), t, r[0] if len(r) > 0 else 0, r[1] if len(r) > 1 else 0], dtype=np.float32)
+        assert np.array_equal(mine.view(np.uint32), o.view(np.uint32)), c
+
+
+def test_transcendental_spot_values(orc):
+    L = orc.lib()
+    assert abs(L.orc_pow(27.0, 1.0 / 3.0) - 3.0000005) < 1e-6     # the reference GL's pow is ~2 ulp off here
+    assert L.orc_pow(0.0, 5.0) == 0.0
+    assert np.isnan(L.orc_pow(-1.0, 5.0))
+    assert abs(L.orc_acos(0.3) - 1.2659477) < 1e-6               # low-accuracy acos polynomial (true 1.2661037)
+    assert L.orc_cos(0.0) == 1.0
+
+
+def test_work_counters_match_reference_profile(orc, rt):
+    """Per-pixel call counts of the reference shader at 800x800 as shipped, measured on the
+    instrumented shader: trace 4.115, bounding tests 20.58, sphere 1.992, torus 0.331,
+    segments 2.974, phong 1.009, refraction pushes 0.521, reflection pushes 1.453, no drops,
+    cubic trig/Cardano 0.153/0.178."""
+    cam = rt.default_camera()
+    out = orc.render(rt.default_scene(), cam.matrix(), cam.focal_length, 800, 800, want_events=True)
+    names, _ = rt.event_table()
+    ev = dict(zip(names, (out["events"] / 640000.0).tolist()))
+    assert abs(ev["trace"] - 4.115) < 5e-4
+    assert abs(ev["bound_cull_disc"] + ev["bound_tbound"] - 20.58) < 5e-3
+    assert abs(ev["sphere_call"] - 1.992) < 5e-4
+    assert abs(ev["torus_call"] - 0.331) < 5e-4
+    assert abs(ev["seg_miss"] + ev["seg_hit"] - 2.974) < 5e-4
+    assert abs(ev["phong_full"] + ev["phong_shadowed"] - 1.009) < 5e-4
+    assert abs(ev["refr_push"] - 0.521) < 5e-4
+    assert abs(ev["refl_push"] - 1.453) < 5e-4
+    assert ev["drop"] == 0
+    assert abs(ev["trig"] - 0.153) < 5e-4 and abs(ev["cardano"] - 0.178) < 5e-4
+
+
+def test_event_tables_agree(orc, rt):
+    """The oracle and the library price every event class identically."""
+    _, lib_table = rt.event_table()
+    assert np.array_equal(orc.event_table(), lib_table)
+
+
+def test_oracle_rejects_bad_input(orc, rt):
+    cam = rt.default_camera()
+    bad = rt.default_scene()
+    bad[0]["type"] = 3
+    with pytest.raises(ValueError):
+        orc.render(bad, cam.matrix(), 2.0, 8, 8)
