@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixel-paths/s (and fps) of the per-pixel ray-tracing path on the
+default scene at 3840x2160, max bounce depth 8, on 1/2/4/8 MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one full 3840x2160 frame through the HIP path (strict flavour: the frame is
+bit-identical to the reference shader's).  Scene and camera are resident on the GPU before
+the timed region; the frame stays in HBM on GPU 0.  With N GPUs the frame is cut into
+interleaved 16-row bands, each rank renders its bands, rank 0 gathers them with RCCL
+(torch.distributed "nccl") and scatters them into place; total work per step is fixed, so
+scaling is "strong".
+
+Extra objects in the JSON line:
+  roofline     FP32-VALU roofline of the render kernel: algorithmic FLOPs of the frame
+               (event counters of the instrumented kernel x the shader-source FLOP table)
+               / average kernel time measured with HIP events on the launch stream,
+               against the 157.3 TFLOP/s FP32 vector peak (78.6 without packed FMA).
+  cpu_baseline the CPU oracle (the reference shader restated in C, OpenMP) timed on this
+               box's host cores on a bounded sample of the same workload, rank 0 at N=1.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+W, H = 3840, 2160
+MAX_DEPTH, STACK_SIZE, SHADOW_HOPS = 8, 3, 2
+PEAK_FP32_VECTOR_TFLOPS = 157.3     # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+PEAK_FP32_FMA_TFLOPS = 78.6         # same without packed math
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--fast-math", action="store_true", help="bench the fast flavour instead of the strict one")
+    ap.add_argument("--stack-size", type=int, default=STACK_SIZE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rt355
+    from importlib import import_module
+    tiling = import_module("ray-tracing_amd.tiling")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = rt355.init(local_rank)
+    scene, cam = rt355.default_scene(), rt355.default_camera()
+    rt355.set_scene(scene)
+    flags = rt355.api.FLAG_FAST_MATH if args.fast_math else 0
+    params = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
+                                   shadow_hops=SHADOW_HOPS, flags=flags, part=rank, nparts=world)
+    # a real (non-null) stream: the kernels, the RCCL hand-off and the timing events all go
+    # through it (a NULL stream argument would select the library's private stream, which
+    # torch events do not see)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+    assert stream.cuda_stream != 0
+    pptr = ctypes.addressof(params)
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(lib.rt_last_error().decode())
+
+    def render_part(part, nparts, out):
+        check(lib.rt_render_device(pptr, out.data_ptr(), out.numel(), sptr, 0))
+
+    def assemble(gathered, image):
+        check(lib.rt_assemble_device(gathered.data_ptr(), image.data_ptr(), W, H, world, 4, sptr))
+
+    pipe = tiling.BandPipeline(H, W, 4, torch.uint8, dev, dist if world > 1 else None, render_part, assemble)
+    image = pipe.image
+
+    def run(steps):
+        for _ in range(steps):
+            pipe.step()
+        pipe.flush()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    run(args.steps)
+    e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stream_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        mpix = W * H / 1e6
+        result = {
+            "metric": "Mpixel-paths/s at 3840x2160 (default scene, max bounce depth 8)",
+            "value": mpix / (ms_per_step * 1e-3), "unit": "Mpixel-paths/s", "fps": 1e3 / ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (the reference's default scene and camera; no dataset exists)",
+            "config": {"workload": "default main.py scene, 3840x2160, max_depth 8, stack_size %d, 2 shadow hops, 1 spp"
+                                   % args.stack_size,
+                       "numerics": "fast" if args.fast_math else "strict (bit-identical to the reference shader)",
+                       "tiling": "%d x interleaved 16-row bands, RCCL gather to GPU 0" % world if world > 1 else "single GPU"},
+        }
+
+    # ---- kernel-only measurements, single GPU: roofline + cpu baseline
+    if world == 1 and rank == 0:
+        full = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
+                                     shadow_hops=SHADOW_HOPS, flags=flags)
+        import numpy as np
+        ev = np.zeros(lib.rt_event_count(), dtype=np.uint64)
+        check(lib.rt_count_events(ctypes.addressof(full), ev.ctypes.data))
+        flops = rt355.frame_flops(ev)
+        kernel_ms = stream_ms / args.steps          # back-to-back launches of the one kernel on this stream
+        tim = rt355.api.RtTiming()
+        check(lib.rt_render_device(ctypes.addressof(full), image.data_ptr(), image.numel(), sptr, 1))
+        torch.cuda.synchronize()
+        check(lib.rt_get_timing(ctypes.addressof(tim)))
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "frac_of_unpacked_fma_peak": achieved / PEAK_FP32_FMA_TFLOPS,
+            "traffic": None,
+            "kernel": "rt_kernel<%d,false> (%s)" % (tim.pending_cap, "fast" if args.fast_math else "strict"),
+            "kernel_ms_avg": kernel_ms, "kernel_ms_single_launch": tim.kernel_ms,
+            "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H),
+            "vgprs": tim.vgprs, "lds_bytes": tim.lds_bytes,
+        }
+        if not args.no_cpu_baseline:
+            import rt_oracle as orc
+            threads = min(os.cpu_count() or 1, 16)
+            frames = 0
+            orc.render(scene, cam.matrix(), cam.focal_length, W, H // 8, max_depth=MAX_DEPTH,
+                       stack_size=args.stack_size, shadow_hops=SHADOW_HOPS, nthreads=threads)   # warm up
+            c0 = time.perf_counter()
+            while frames < 3 or (time.perf_counter() - c0 < 2.0 and frames < 20):
+                orc.render(scene, cam.matrix(), cam.focal_length, W, H, max_depth=MAX_DEPTH,
+                           stack_size=args.stack_size, shadow_hops=SHADOW_HOPS, nthreads=threads)
+                frames += 1
+            cpu_s = (time.perf_counter() - c0) / frames
+            result["cpu_baseline"] = {
+                "value": W * H / 1e6 / cpu_s, "unit": "Mpixel-paths/s", "cores": threads, "kind": "port",
+                "sample": "%d full 3840x2160 frames of the same workload (%.2f s each) on %d OpenMP threads"
+                          % (frames, cpu_s, threads),
+            }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

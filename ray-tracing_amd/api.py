@@ -16,7 +16,7 @@ import numpy as np
 from .camera import Camera
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_PKG_DIR, "librt355.so")
 
 RT_MAX_OBJECTS = 1024
 RT_MAX_PENDING = 16

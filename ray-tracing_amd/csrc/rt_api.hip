@@ -128,6 +128,8 @@ KParams make_kparams(const rt_params *p)
     k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
+    for (int i = 0; i < 16; ++i)
+        k.sample_off[i] = i < p->spp_grid ? (float)(((double)i + 0.5) / (double)p->spp_grid - 0.5) : 0.0f;
     k.scene = g.layout;
     return k;
 }
@@ -214,12 +216,13 @@ int rt_set_scene(const rt_object *objs, int n)
     std::vector<float> blob((size_t)L.total_dwords + 4, 0.0f);
     int *kind = reinterpret_cast<int *>(blob.data() + L.off_kind);
     int slot = 0;
+    if (n & 1) blob[8 * (n >> 1) + 1 + 6] = -INFINITY;   // pad record of the last pair: disc = -inf
     for (int i = 0; i < n; ++i) {
         const rt_object &o = objs[i];
         // bounding radius: radius, or major + minor for a torus (fragment_shader.glsl:391-396)
         float br = o.type == 1 ? o.radius : o.major_radius + o.minor_radius;
-        float *b = blob.data() + 4 * i;
-        b[0] = o.center[0]; b[1] = o.center[1]; b[2] = o.center[2]; b[3] = br * br;
+        float *b = blob.data() + 8 * (i >> 1) + (i & 1);
+        b[0] = o.center[0]; b[2] = o.center[1]; b[4] = o.center[2]; b[6] = br * br;
         float *m = blob.data() + L.off_material + 8 * i;
         m[0] = o.color[0]; m[1] = o.color[1]; m[2] = o.color[2]; m[3] = o.reflectivity;
         m[4] = o.transparency; m[5] = o.refractive_index;

@@ -334,7 +334,58 @@ DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, flo
 }
 
 // ------------------------------------------------------------------ trace (fragment_shader.glsl:379-435)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Centre of object `id` from the pair-interleaved bound records.
+DEV void object_centre(const float *lds, int id, float &cx, float &cy, float &cz)
+{
+    const float *p = lds + 8 * (id >> 1) + (id & 1);
+    cx = p[0]; cy = p[2]; cz = p[4];
+}
+
+// Exact test of one object whose bounding test did not reject it (:405-425).
+template <bool DEBUG>
+DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int i, float a,
+                        float ocx, float ocy, float ocz, float b, float c, float disc,
+                        float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
+{
+    CNT(EV_BOUND_TBOUND);
+    // t_bound > closest.t can only hold once something has been hit: while closest.t is
+    // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
+    if (bt < 1e30f) {
+        float t_bound = -b - rt_sqrt(disc);
+        if (t_bound > bt) return;
+    }
+    int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
+    float t; bool hit;
+    if (kd < 0) {
+        // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
+        CNT(EV_SPHERE_CALL);
+        float b2 = 2.0f * b;
+        float ds = b2 * b2 - (4.0f * a) * c;
+        hit = false; t = 0.0f;
+        if (!(ds < 0.0f)) {
+            float sq = rt_sqrt(ds);
+            float two_a = 2.0f * a;
+            CNT(EV_SPHERE_ROOT);
+            t = rt_div(-b2 - sq, two_a);
+            if (t < 0.0f) { CNT(EV_SPHERE_ROOT); t = rt_div(-b2 + sq, two_a); }
+            hit = t > 0.001f;
+            if (hit) CNT(EV_SPHERE_HIT);
+        }
+    } else {
+        TorusFrame f = load_torus(lds, L.off_torus, kd);
+        hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
+        if (hit) CNT(EV_TORUS_HIT);
+    }
+    if (hit && t < bt) { bt = t; bid = i; }
+}
+
 // Closest hit as (t, id): id -1 none, 0..n-1 scene object, n ground plane.
+// The bounding test (:399-402) runs on two objects per instruction with packed FP32 math
+// (v_pk_add/v_pk_mul: each half is an ordinary correctly rounded binary32 operation, so
+// the values are those of the scalar form); object order, and with it the tie rule "first
+// index wins" (:423), is kept by resolving the pair's candidates in index order.
 template <bool DEBUG>
 DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
                        float ox, float oy, float oz, float dx, float dy, float dz,
@@ -343,45 +394,37 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     CNT(EV_TRACE);
     float bt = 1e30f;
     int bid = -1;
-    const float4 *bound = reinterpret_cast<const float4 *>(lds);
-    const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
+    const float4 *pairs = reinterpret_cast<const float4 *>(lds);
     const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
     const int n = L.n;
-    for (int i = 0; i < n; ++i) {
-        float4 q = bound[i];                          // LDS broadcast: same address in every lane
-        float ocx = ox - q.x, ocy = oy - q.y, ocz = oz - q.z;
-        float b = dot3(ocx, ocy, ocz, dx, dy, dz);
-        float oc2 = dot3(ocx, ocy, ocz, ocx, ocy, ocz);
-        float c = oc2 - q.w;
-        float disc = b * b - c;
-        if (DEBUG) { if (kind[i] >= 0) CNT(EV_BOUND_TORUS_RADIUS); }
-        if (disc < 0.0f) { CNT(EV_BOUND_CULL_DISC); continue; }
-        CNT(EV_BOUND_TBOUND);
-        float t_bound = -b - rt_sqrt(disc);
-        if (t_bound > bt) continue;
-        int kd = kind[i];
-        float t; bool hit;
-        if (kd < 0) {
-            // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
-            CNT(EV_SPHERE_CALL);
-            float b2 = 2.0f * b;
-            float ds = b2 * b2 - (4.0f * a) * c;
-            hit = false; t = 0.0f;
-            if (!(ds < 0.0f)) {
-                float sq = rt_sqrt(ds);
-                float two_a = 2.0f * a;
-                CNT(EV_SPHERE_ROOT);
-                t = rt_div(-b2 - sq, two_a);
-                if (t < 0.0f) { CNT(EV_SPHERE_ROOT); t = rt_div(-b2 + sq, two_a); }
-                hit = t > 0.001f;
-                if (hit) CNT(EV_SPHERE_HIT);
-            }
-        } else {
-            TorusFrame f = load_torus(lds, L.off_torus, kd);
-            hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
-            if (hit) CNT(EV_TORUS_HIT);
+    const int npairs = (n + 1) >> 1;
+    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+    float4 A = make_float4(0, 0, 0, 0), B = A;
+    if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
+    for (int j = 0; j < npairs; ++j) {
+        // next pair's record is requested before this pair is worked on (LDS broadcast read)
+        const int jn = (j + 1 < npairs) ? j + 1 : j;
+        float4 An = pairs[2 * jn], Bn = pairs[2 * jn + 1];
+        v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
+        v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
+        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
+        v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+        v2f c = oc2 - br2;
+        v2f disc = b * b - c;
+        if (DEBUG) {
+            const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
+            if (kind[2 * j] >= 0) CNT(EV_BOUND_TORUS_RADIUS);
+            if (2 * j + 1 < n && kind[2 * j + 1] >= 0) CNT(EV_BOUND_TORUS_RADIUS);
+            if (disc.x < 0.0f) CNT(EV_BOUND_CULL_DISC);
+            if (2 * j + 1 < n && disc.y < 0.0f) CNT(EV_BOUND_CULL_DISC);
         }
-        if (hit && t < bt) { bt = t; bid = i; }
+        if (!(disc.x < 0.0f))
+            test_candidate<DEBUG>(lds, L, polish, 2 * j, a, ocx.x, ocy.x, ocz.x, b.x, c.x, disc.x, dx, dy, dz, bt, bid, cnt);
+        // an odd object count is padded with a record whose radius^2 is -inf: disc = -inf
+        if (!(disc.y < 0.0f))
+            test_candidate<DEBUG>(lds, L, polish, 2 * j + 1, a, ocx.y, ocy.y, ocz.y, b.y, c.y, disc.y, dx, dy, dz, bt, bid, cnt);
+        A = An; B = Bn;
     }
     // intersect_plane (:107-123): y = -1, two-sided
     CNT(EV_PLANE_CALL);
@@ -410,7 +453,10 @@ template <int CAP> struct Pending {
 enum { ST_PATH = 0, ST_SHADOW = 1 };
 
 template <int CAP, bool DEBUG>
-__global__ __launch_bounds__(256)
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(256, RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
@@ -469,13 +515,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     // debug capture
     int seg = 0, cap_nseg = 0; float cap_id = -2.0f, cap_t = 0.0f, cap_depth = 0.0f;
 
-    auto start_sample = [&](int s) {
+    // stratified sample positions: offset of sample column/row i from the pixel centre,
+    // (i + 0.5)/N - 0.5 rounded once to binary32 (host-computed table, kp.sample_off)
+    int si = 0, sj = 0;
+    auto start_sample = [&]() {
         // main() (:650-668): pixel centre + stratified offset
-        int si = s % N, sj = s / N;
-        float offx = (float)(((double)si + 0.5) / (double)N - 0.5);
-        float offy = (float)(((double)sj + 0.5) / (double)N - 0.5);
-        float fx = ((float)px + 0.5f) + offx;
-        float fy = ((float)gy + 0.5f) + offy;
+        float fx = ((float)px + 0.5f) + kp.sample_off[si];
+        float fy = ((float)gy + 0.5f) + kp.sample_off[sj];
         float uvx = rt_div(fx * 2.0f - kp.res_w, kp.res_h);
         float uvy = rt_div(fy * 2.0f - kp.res_h, kp.res_h);
         float rx = (uvx * kp.right[0] + uvy * kp.up[0]) + kp.focal * kp.fwd[0];
@@ -488,7 +534,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         fr = fg = fb = 0.0f; np = 0; state = ST_PATH; seg = 0;
         CNT(EV_PIXEL_PATH);
     };
-    if (active) start_sample(0);
+    if (active) start_sample();
 
     while (active) {
         float t; int id;
@@ -527,15 +573,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
                     float4 m0 = mat[0], m1 = mat[1];
                     mr = m0.x; mg = m0.y; mb = m0.z; m_refl = m0.w; m_transp = m1.x; h_ior = m1.y;
-                    float4 q = reinterpret_cast<const float4 *>(lds)[id];
+                    float qx, qy, qz;
+                    object_centre(lds, id, qx, qy, qz);
                     int kd = reinterpret_cast<const int *>(lds + L.off_kind)[id];
                     if (kd < 0) {
-                        float vx = hx - q.x, vy = hy - q.y, vz = hz - q.z;
+                        float vx = hx - qx, vy = hy - qy, vz = hz - qz;
                         float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
                         nx = vx * rs; ny = vy * rs; nz = vz * rs;
                     } else {
                         TorusFrame f = load_torus(lds, L.off_torus, kd);
-                        float ocx = ox - q.x, ocy = oy - q.y, ocz = oz - q.z;
+                        float ocx = ox - qx, ocy = oy - qy, ocz = oz - qz;
                         float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
                         float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
                         float roz = dot3(ocx, ocy, ocz, f.vx, f.vy, f.vz);
@@ -713,7 +760,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 else { accr = accr + fr; accg = accg + fg; accb = accb + fb; }
                 if (DEBUG && sample == 0) cap_nseg = seg;
                 sample++;
-                if (sample < nsamples) start_sample(sample);
+                si++;
+                if (si == N) { si = 0; sj++; }
+                if (sample < nsamples) start_sample();
                 else active = false;
             }
         }
@@ -786,8 +835,8 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int need = needed_cap(kp);
-    if (need <= 4) return launch_variant<4, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
-    if (need <= 8) return launch_variant<8, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+    if (need <= 3) return launch_variant<3, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+    if (need <= 7) return launch_variant<7, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
     return launch_variant<16, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
 }
 

@@ -5,12 +5,16 @@
 // ---- staged scene ("blob"): what the host packs, what every workgroup copies to LDS ----
 //
 // Layout in dwords, all sections 16-byte aligned:
-//   [0, 4n)              bound[i]    = { cx, cy, cz, bounding_radius^2 }
-//   [4n, 4n + 8n)        material[i] = { r, g, b, reflectivity } { transparency, ior, 0, 0 }
-//   [12n, 12n + 16*nt)   torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
+//   [0, 8*np)            bound[j]    = { cx0 cx1 cy0 cy1 } { cz0 cz1 br0 br1 }: objects 2j and 2j+1
+//                                      interleaved so that the bounding test of both runs as packed
+//                                      FP32 math; br = bounding_radius^2; np = ceil(n/2); an odd n
+//                                      is padded with a record whose br is -inf (never passes)
+//   [.., + 8n)           material[i] = { r, g, b, reflectivity } { transparency, ior, 0, 0 }
+//   [.., + 16*nt)        torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
 //   [.., + n)            kind[i]     = -1 for a sphere, torus slot s >= 0 for a torus
-// Keeping only the 16-byte bound record in the per-object hot loop and everything else
-// behind the bound test is what makes 1024 objects fit in LDS next to several workgroups.
+// Keeping only the 16 bytes per object of the bound record in the per-object hot loop and
+// everything else behind the bound test is what makes 1024 objects fit in LDS next to
+// several workgroups.
 struct SceneLayout {
     int n, ntori;
     int off_material;   // dword offsets
@@ -23,9 +27,10 @@ static inline SceneLayout scene_layout(int n, int ntori)
 {
     SceneLayout L;
     L.n = n; L.ntori = ntori;
-    L.off_material = 4 * n;
-    L.off_torus = 12 * n;
-    L.off_kind = 12 * n + 16 * ntori;
+    int np = (n + 1) / 2;
+    L.off_material = 8 * np;
+    L.off_torus = L.off_material + 8 * n;
+    L.off_kind = L.off_torus + 16 * ntori;
     L.total_dwords = (L.off_kind + n + 3) & ~3;
     return L;
 }
@@ -43,6 +48,7 @@ struct KParams {
     int out_f32;            // 0: RGBA8, 1: float4
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
+    float sample_off[16];   // (i + 0.5)/spp - 0.5 for i < spp, rounded to binary32
     SceneLayout scene;
 };
 

@@ -66,3 +66,58 @@ def render_distributed(render_part, height: int, width: int, channels: int, dtyp
         return torch.stack(chunks, 0)
     dist.gather(mine, gather_list=None, dst=0)
     return None
+
+
+class BandPipeline:
+    """Frames in flight over all ranks: rank r renders its bands of frame k, the gather of
+    frame k to rank 0 is started asynchronously, and frame k-1's bands are scattered into
+    the final image while frame k renders (two buffers per rank).  The only collective on
+    the data path is the gather; there is no exchange during rendering.
+
+    render_part(part, nparts, out)   fills the (padded_rows, w, c) tensor `out` with this
+                                     rank's packed bands (asynchronously on the current
+                                     stream when `out` lives on a GPU)
+    assemble(gathered, image)        rank 0 only: (nparts, padded_rows, w, c) -> (h, w, c)
+    """
+
+    def __init__(self, height, width, channels, dtype, device, dist, render_part, assemble):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.h, self.w = height, width
+        self.render_part, self.assemble = render_part, assemble
+        rows = padded_part_rows(height, self.world)
+        self.mine = [torch.zeros((rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
+        self.image = torch.empty((height, width, channels), dtype=dtype, device=device) if self.rank == 0 else None
+        if self.rank == 0 and self.world > 1:
+            self.chunks = [[torch.empty_like(self.mine[0]) for _ in range(self.world)] for _ in range(2)]
+            self.gathered = torch.empty((self.world, rows, width, channels), dtype=dtype, device=device)
+        else:
+            self.chunks, self.gathered = None, None
+        self.prev = None
+        self.k = 0
+
+    def _finish(self, k, work):
+        work.wait()
+        if self.rank == 0:
+            self.torch.stack(self.chunks[k % 2], 0, out=self.gathered)
+            self.assemble(self.gathered, self.image)
+
+    def step(self):
+        k = self.k
+        self.k += 1
+        if self.world == 1:
+            self.render_part(0, 1, self.image)
+            return
+        buf = self.mine[k % 2]
+        self.render_part(self.rank, self.world, buf)
+        work = self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0, async_op=True)
+        if self.prev is not None:
+            self._finish(*self.prev)
+        self.prev = (k, work)
+
+    def flush(self):
+        if self.prev is not None:
+            self._finish(*self.prev)
+            self.prev = None

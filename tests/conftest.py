@@ -4,6 +4,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (loaded before librt355 so that the process holds ONE HIP runtime: torch ships its own copy)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):

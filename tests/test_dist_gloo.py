@@ -46,7 +46,19 @@ def _worker(rank, world, port, w, h, q):
 
     g = tiling.render_distributed(render_part, h, w, 4, torch.uint8, "cpu", dist)
     if rank == 0:
-        q.put(tiling.assemble_numpy(g.numpy(), h, world))
+        single = tiling.assemble_numpy(g.numpy(), h, world)
+
+    # the pipelined form bench.py drives: several frames in flight, gather overlapped with render
+    def assemble(gathered, image):
+        image.copy_(torch.from_numpy(tiling.assemble_numpy(gathered.numpy(), h, world)))
+
+    pipe = tiling.BandPipeline(h, w, 4, torch.uint8, "cpu", dist, render_part, assemble)
+    for _ in range(3):
+        pipe.step()
+    pipe.flush()
+    if rank == 0:
+        assert np.array_equal(pipe.image.numpy(), single)
+        q.put(single)
     dist.barrier()
     dist.destroy_process_group()
 

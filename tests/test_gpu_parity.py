@@ -218,4 +218,4 @@ def test_4k_headline_properties(gpu_rt):
     img = gpu_rt.render_rgba(scene, cam, 3840, 2160, bottom_up=True, **opts(meta))
     assert sha(img) == meta["sha256_rgba8"]
     t = gpu_rt.timing()
-    assert t["kernel_ms"] > 0 and t["pending_cap"] == 4
+    assert t["kernel_ms"] > 0 and t["pending_cap"] == 3
