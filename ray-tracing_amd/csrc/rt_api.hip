@@ -226,6 +226,10 @@ int rt_set_scene(const rt_object *objs, int n)
         float *m = blob.data() + L.off_material + 8 * i;
         m[0] = o.color[0]; m[1] = o.color[1]; m[2] = o.color[2]; m[3] = o.reflectivity;
         m[4] = o.transparency; m[5] = o.refractive_index;
+        // Fresnel constants against air (fragment_shader.glsl:525-528 with n1 = 1, n2 = ior)
+        float q = (1.0f - o.refractive_index) / (1.0f + o.refractive_index);
+        m[6] = q * q;
+        m[7] = 1.0f / o.refractive_index;
         if (o.type == 1) { kind[i] = -1; continue; }
         kind[i] = slot;
         // torus frame (fragment_shader.glsl:315-317): w = normalize(normal),

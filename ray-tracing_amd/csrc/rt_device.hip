@@ -27,6 +27,7 @@
 //   * a lane that finishes a sample starts its next stratified sample immediately.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rt_types.h"
 
@@ -45,29 +46,28 @@ DEV float bits_f(uint32_t u) { return __uint_as_float(u); }
 DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
 
 #ifdef RT_FAST
+// fast flavour: hardware reciprocal / rsqrt / sqrt (1 ulp), FMA contraction (compile flag)
 DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
-DEV float rt_pow(float x, float y)
-{
-    // v_log_f32 / v_exp_f32 are base 2; pow(0, y>0) = 0 falls out of log2(0) = -inf.
-    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-}
-DEV float rt_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
 #else
+// strict flavour: correctly rounded, as the reference's CPU GL computes them
 DEV float rt_div(float a, float b) { return a / b; }
 DEV float rt_sqrt(float a) { return __builtin_sqrtf(a); }
 DEV float rt_rsq(float a) { return 1.0f / __builtin_sqrtf(a); }
+#endif
 
 // pow(x, y) = exp2(y * log2 x) with the polynomial kernels the reference's CPU GL runs
 // (mantissa/exponent split + degree-4 minimax in ((m-1)/(m+1))^2; floor/fraction split +
-// degree-5 minimax), multiply-adds fused.
+// degree-5 minimax), multiply-adds fused.  Both flavours use them: the reference's pow is
+// ~2 ulp off and its acos 7e-5 off, and the torus solver amplifies such differences, so a
+// more accurate pow would move torus pixels away from the reference.
 DEV float lp_log2(float x)
 {
     uint32_t i = f_bits(x);
     float e = (float)((int)((i & 0x7f800000u) >> 23) - 127);
     float m = bits_f((i & 0x007fffffu) | 0x3f800000u);
-    float y = (m - 1.0f) / (m + 1.0f);
+    float y = rt_div(m - 1.0f, m + 1.0f);
     float z = y * y;
     float z2 = z * z;
     float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f), 0x1.715476p+1f);
@@ -82,8 +82,7 @@ DEV float lp_log2(float x)
 DEV float rt_pow(float x, float y)
 {
     if (!(x < 0.0f || x > 0.0f)) return 0.0f;
-    float t = lp_log2(x) * y;
-    if (t != t) return t;
+    float t = lp_log2(x) * y;              // NaN for x < 0, and NaN passes through the clamps
     t = (128.0f < t) ? 128.0f : t;
     t = (-0x1.fbfffep+6f > t) ? -0x1.fbfffep+6f : t;
     float fl = __builtin_floorf(t);
@@ -127,7 +126,6 @@ DEV float rt_cos(float x)
     res = (res > -1.0f) ? res : -1.0f;
     return res;
 }
-#endif
 
 // acos as the GLSL front end lowers it (both flavours; it is six cheap ops and a sqrt).
 DEV float rt_acos(float x)
@@ -403,14 +401,15 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     float4 A = make_float4(0, 0, 0, 0), B = A;
     if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
     for (int j = 0; j < npairs; ++j) {
-        // next pair's record is requested before this pair is worked on (LDS broadcast read)
-        const int jn = (j + 1 < npairs) ? j + 1 : j;
-        float4 An = pairs[2 * jn], Bn = pairs[2 * jn + 1];
         v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
         v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
         v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
         v2f c = oc2 - br2;
+        // the record is consumed: request the next pair's (LDS broadcast read) into the same
+        // registers; its latency is covered by the rest of this iteration
+        const int jn = (j + 1 < npairs) ? j + 1 : j;
+        A = pairs[2 * jn]; B = pairs[2 * jn + 1];
+        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
         v2f disc = b * b - c;
         if (DEBUG) {
             const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
@@ -424,7 +423,6 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
         // an odd object count is padded with a record whose radius^2 is -inf: disc = -inf
         if (!(disc.y < 0.0f))
             test_candidate<DEBUG>(lds, L, polish, 2 * j + 1, a, ocx.y, ocy.y, ocz.y, b.y, c.y, disc.y, dx, dy, dz, bt, bid, cnt);
-        A = An; B = Bn;
     }
     // intersect_plane (:107-123): y = -1, two-sided
     CNT(EV_PLANE_CALL);
@@ -452,11 +450,18 @@ template <int CAP> struct Pending {
 // ------------------------------------------------------------------ the kernel
 enum { ST_PATH = 0, ST_SHADOW = 1 };
 
-template <int CAP, bool DEBUG>
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2
 #endif
-__global__ __launch_bounds__(256, RT_WAVES_PER_EU)
+#ifndef RT_WAVES_PER_EU_LDSP
+#define RT_WAVES_PER_EU_LDSP 4
+#endif
+// LDSP: the pending-ray slots live in LDS ([slot][field][thread], one conflict-free dword
+// column per lane) instead of registers; used where that buys a wave of occupancy.
+// MULTI: more than one sample per pixel (sample loop + accumulators); the single-sample
+// kernel carries neither.
+template <int CAP, bool DEBUG, bool LDSP, bool MULTI>
+__global__ __launch_bounds__(256, LDSP ? RT_WAVES_PER_EU_LDSP : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
@@ -484,7 +489,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     bool active = px < kp.w && row < kp.h;
     const int gy = kp.bottom_up ? row : (kp.h - 1 - row); // GL row (0 = bottom)
 
-    const int N = kp.spp;
+    const int N = MULTI ? kp.spp : 1;
     const int nsamples = N * N;
     const float inv_spp = 1.0f / (float)nsamples;
 
@@ -496,12 +501,14 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     float accr = 0, accg = 0, accb = 0;                    // sum over samples
     int sample = 0;
     int np = 0;                                            // pending refraction rays
-    Pending<CAP> pend;
+    Pending<LDSP ? 1 : CAP> pend;
 #pragma unroll
-    for (int k = 0; k < CAP; ++k) {
+    for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
         pend.ox[k] = pend.oy[k] = pend.oz[k] = 0; pend.dx[k] = pend.dy[k] = pend.dz[k] = 0;
         pend.tx[k] = pend.ty[k] = pend.tz[k] = 0; pend.ior[k] = 1; pend.depth[k] = 0;
     }
+    // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
+    float *pend_lds = lds + ((L.total_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit
     float hx = 0, hy = 0, hz = 0;            // hit position
@@ -520,8 +527,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     int si = 0, sj = 0;
     auto start_sample = [&]() {
         // main() (:650-668): pixel centre + stratified offset
-        float fx = ((float)px + 0.5f) + kp.sample_off[si];
-        float fy = ((float)gy + 0.5f) + kp.sample_off[sj];
+        float fx = (float)px + 0.5f, fy = (float)gy + 0.5f;
+        if (MULTI) { fx = fx + kp.sample_off[si]; fy = fy + kp.sample_off[sj]; }
         float uvx = rt_div(fx * 2.0f - kp.res_w, kp.res_h);
         float uvy = rt_div(fy * 2.0f - kp.res_h, kp.res_h);
         float rx = (uvx * kp.right[0] + uvy * kp.up[0]) + kp.focal * kp.fwd[0];
@@ -562,17 +569,19 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 CNT(EV_SEG_HIT);
                 // ---- HitInfo of the winner (:93-100, :122-141, :357-372)
                 hx = ox + t * dx; hy = oy + t * dy; hz = oz + t * dz;
-                float h_ior;
+                float h_ior, h_r0, h_eta_in;
                 if (id == L.n) {
                     nx = 0.0f; ny = 1.0f; nz = 0.0f;
                     float s = __builtin_floorf(hx) + __builtin_floorf(hz);
                     float two_fl = 2.0f * __builtin_floorf(s * 0.5f);
                     float col = (s == two_fl) ? 0.9f : 0.1f;
                     mr = mg = mb = col; m_refl = 0.05f; m_transp = 0.0f; h_ior = 1.0f;
+                    h_r0 = 0.0f; h_eta_in = 1.0f;         // ((1-1)/(1+1))^2 and 1/1
                 } else {
                     const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
                     float4 m0 = mat[0], m1 = mat[1];
                     mr = m0.x; mg = m0.y; mb = m0.z; m_refl = m0.w; m_transp = m1.x; h_ior = m1.y;
+                    h_r0 = m1.z; h_eta_in = m1.w;
                     float qx, qy, qz;
                     object_centre(lds, id, qx, qy, qz);
                     int kd = reinterpret_cast<const int *>(lds + L.off_kind)[id];
@@ -610,8 +619,18 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 float onx = entering ? nx : -nx, ony = entering ? ny : -ny, onz = entering ? nz : -nz;
                 dni = dot3(dx, dy, dz, onx, ony, onz);
                 float cos_t = __builtin_fabsf(dni);
-                float r0 = rt_div(n1 - n2, n1 + n2); r0 = r0 * r0;
-                eta = rt_div(n1, n2);
+                // r0 = ((n1-n2)/(n1+n2))^2 and eta = n1/n2 (:525-528).  Between air (1.0) and the
+                // object's medium both are per-object constants, staged with the material by the
+                // host with the same binary32 operations: entering from air n1 = 1, n2 = ior;
+                // leaving n1 = ior, n2 = 1 (r0 is the same value both ways: the quotient only
+                // changes sign, and eta = ior / 1 = ior).  Only a ray that enters from a medium
+                // other than air computes them here.
+                float r0 = h_r0;
+                eta = entering ? h_eta_in : h_ior;
+                if (entering && cur_ior != 1.0f) {
+                    r0 = rt_div(n1 - n2, n1 + n2); r0 = r0 * r0;
+                    eta = rt_div(n1, n2);
+                }
                 float sin_t2 = (eta * eta) * (1.0f - cos_t * cos_t);
                 if (sin_t2 > 1.0f) { CNT(EV_FRESNEL_TIR); F = 1.0f; }
                 else { CNT(EV_FRESNEL_FULL); F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_t, 5.0f); }
@@ -716,12 +735,20 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         float uy = ((thy * omf) * m_transp) * mg;
                         float uz = ((thz * omf) * m_transp) * mb;
                         const int slot = np;
+                        if (LDSP) {
+                            float *q = pend_lds + slot * (11 * 256);
+                            q[0 * 256] = qx; q[1 * 256] = qy; q[2 * 256] = qz;
+                            q[3 * 256] = rx; q[4 * 256] = ry; q[5 * 256] = rz;
+                            q[6 * 256] = ux; q[7 * 256] = uy; q[8 * 256] = uz;
+                            q[9 * 256] = n2; q[10 * 256] = __int_as_float(depth + 1);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < CAP; ++k) {
-                            SEL_STORE(pend.ox, qx); SEL_STORE(pend.oy, qy); SEL_STORE(pend.oz, qz);
-                            SEL_STORE(pend.dx, rx); SEL_STORE(pend.dy, ry); SEL_STORE(pend.dz, rz);
-                            SEL_STORE(pend.tx, ux); SEL_STORE(pend.ty, uy); SEL_STORE(pend.tz, uz);
-                            SEL_STORE(pend.ior, n2); SEL_STORE(pend.depth, depth + 1);
+                            for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
+                                SEL_STORE(pend.ox, qx); SEL_STORE(pend.oy, qy); SEL_STORE(pend.oz, qz);
+                                SEL_STORE(pend.dx, rx); SEL_STORE(pend.dy, ry); SEL_STORE(pend.dz, rz);
+                                SEL_STORE(pend.tx, ux); SEL_STORE(pend.ty, uy); SEL_STORE(pend.tz, uz);
+                                SEL_STORE(pend.ior, n2); SEL_STORE(pend.depth, depth + 1);
+                            }
                         }
                         np++;
                     } else if (valid) CNT(EV_DROP);
@@ -747,23 +774,34 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             if (np > 0) {
                 np--;
                 const int slot = np;
+                if (LDSP) {
+                    const float *q = pend_lds + slot * (11 * 256);
+                    ox = q[0 * 256]; oy = q[1 * 256]; oz = q[2 * 256];
+                    dx = q[3 * 256]; dy = q[4 * 256]; dz = q[5 * 256];
+                    thx = q[6 * 256]; thy = q[7 * 256]; thz = q[8 * 256];
+                    cur_ior = q[9 * 256]; depth = __float_as_int(q[10 * 256]);
+                } else {
 #pragma unroll
-                for (int k = 0; k < CAP; ++k) {
-                    SEL_LOAD(ox, pend.ox); SEL_LOAD(oy, pend.oy); SEL_LOAD(oz, pend.oz);
-                    SEL_LOAD(dx, pend.dx); SEL_LOAD(dy, pend.dy); SEL_LOAD(dz, pend.dz);
-                    SEL_LOAD(thx, pend.tx); SEL_LOAD(thy, pend.ty); SEL_LOAD(thz, pend.tz);
-                    SEL_LOAD(cur_ior, pend.ior); SEL_LOAD(depth, pend.depth);
+                    for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
+                        SEL_LOAD(ox, pend.ox); SEL_LOAD(oy, pend.oy); SEL_LOAD(oz, pend.oz);
+                        SEL_LOAD(dx, pend.dx); SEL_LOAD(dy, pend.dy); SEL_LOAD(dz, pend.dz);
+                        SEL_LOAD(thx, pend.tx); SEL_LOAD(thy, pend.ty); SEL_LOAD(thz, pend.tz);
+                        SEL_LOAD(cur_ior, pend.ior); SEL_LOAD(depth, pend.depth);
+                    }
                 }
             } else {
                 // path finished: next stratified sample of this pixel, or done
-                if (nsamples == 1) { accr = fr; accg = fg; accb = fb; }
-                else { accr = accr + fr; accg = accg + fg; accb = accb + fb; }
                 if (DEBUG && sample == 0) cap_nseg = seg;
-                sample++;
-                si++;
-                if (si == N) { si = 0; sj++; }
-                if (sample < nsamples) start_sample();
-                else active = false;
+                if (MULTI) {
+                    accr = accr + fr; accg = accg + fg; accb = accb + fb;
+                    sample++;
+                    si++;
+                    if (si == N) { si = 0; sj++; }
+                    if (sample < nsamples) start_sample();
+                    else active = false;
+                } else {
+                    active = false;
+                }
             }
         }
     }
@@ -772,7 +810,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     const bool in_frame = px < kp.w && row < kp.h;
     if (!DEBUG) {
         if (in_frame) {
-            if (nsamples > 1) { accr = accr * inv_spp; accg = accg * inv_spp; accb = accb * inv_spp; }
+            if (MULTI) { accr = accr * inv_spp; accg = accg * inv_spp; accb = accb * inv_spp; }
+            else { accr = fr; accg = fg; accb = fb; }
             size_t o = (size_t)packed_row * kp.w + px;
             if (kp.out_f32) {
                 reinterpret_cast<float4 *>(out)[o] = make_float4(accr, accg, accb, 1.0f);
@@ -796,12 +835,14 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG>
+template <int CAP, bool DEBUG, bool LDSP, bool MULTI>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
-    auto kfn = rt_kernel<CAP, DEBUG>;
+    auto kfn = rt_kernel<CAP, DEBUG, LDSP, MULTI>;
     size_t lds = (size_t)kp.scene.total_dwords * 4 + (DEBUG ? EV_COUNT * 4 : 0);
+    if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
+    if (const char *pad = getenv("RT_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
@@ -835,16 +876,28 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int need = needed_cap(kp);
-    if (need <= 3) return launch_variant<3, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
-    if (need <= 7) return launch_variant<7, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
-    return launch_variant<16, false>(kp, d_scene, d_out, nullptr, nullptr, s, info);
+    static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
+    const bool multi = kp.spp > 1;
+#define RT_LAUNCH(CAP_, LDSP_)                                                                              \
+    (multi ? launch_variant<CAP_, false, LDSP_, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)       \
+           : launch_variant<CAP_, false, LDSP_, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+    if (need <= 3) {
+        // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
+        // CU next to a small scene, and frees the registers for a fourth wave per SIMD
+        size_t lds = (size_t)kp.scene.total_dwords * 4 + 3 * 11 * 256 * 4;
+        if (!no_ldsp && lds <= 40 * 1024) return RT_LAUNCH(3, true);
+        return RT_LAUNCH(3, false);
+    }
+    if (need <= 7) return RT_LAUNCH(7, false);
+    return RT_LAUNCH(16, false);
+#undef RT_LAUNCH
 }
 
 int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events, float *d_capture,
                  void *stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return launch_variant<16, true>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
+    return launch_variant<16, true, false, true>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
 }
 
 }  // namespace RT_NS

@@ -9,7 +9,7 @@
 //                                      interleaved so that the bounding test of both runs as packed
 //                                      FP32 math; br = bounding_radius^2; np = ceil(n/2); an odd n
 //                                      is padded with a record whose br is -inf (never passes)
-//   [.., + 8n)           material[i] = { r, g, b, reflectivity } { transparency, ior, 0, 0 }
+//   [.., + 8n)           material[i] = { r, g, b, reflectivity } { transparency, ior, r0, 1/ior }: r0 = ((1-ior)/(1+ior))^2
 //   [.., + 16*nt)        torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
 //   [.., + n)            kind[i]     = -1 for a sphere, torus slot s >= 0 for a torus
 // Keeping only the 16 bytes per object of the bound record in the per-object hot loop and
