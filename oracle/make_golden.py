@@ -81,6 +81,10 @@ def cases():
         "mixed1022_160_d2": (lambda: rt355.mixed_scene(1022), rt355.mixed_camera(), 160, 90, 2, 3, 2, "full"),
         "mixed200_240_d5s5": (lambda: rt355.mixed_scene(200), rt355.mixed_camera(), 240, 135, 5, 5, 2, "full"),
     }
+    # random nasty scenes (rt355.random_scene): pin the restatement beyond the hand-picked cases
+    for seed in range(8):
+        sc, cam, o = rt355.random_scene(seed)
+        out[f"random_{seed}"] = ((lambda sc=sc: sc), cam, 160, 120, o["max_depth"], o["stack_size"], o["shadow_hops"], "full")
     return out
 
 

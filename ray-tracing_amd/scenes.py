@@ -124,3 +124,31 @@ def mixed_scene(n: int = 1024, seed: int = 355):
 
 def mixed_camera() -> Camera:
     return Camera(eye=(0.0, 2.5, 5.0), yaw=-90.0, pitch=-10.0, focal_length=2.0)
+
+
+def random_scene(seed: int):
+    """Small random mixed scene + camera + constants, deliberately nasty: overlapping glass
+    objects (rays enter one medium from another), transparent tori, reflectivity 0 and 1,
+    tilted tori, objects cutting the floor.  Returns (scene, camera, opts)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 14))
+    scene = []
+    for _ in range(n):
+        c = [rng.uniform(-2.5, 2.5), rng.uniform(-1.2, 2.0), rng.uniform(-6.0, -1.0)]
+        col = rng.uniform(0.0, 1.0, size=3)
+        kind = rng.integers(0, 4)
+        refl = float(rng.choice([0.0, 0.05, 0.3, 0.8, 1.0]))
+        transp = float(rng.choice([0.0, 0.0, 0.5, 0.9]))
+        if refl + transp > 1.0:
+            transp = round(1.0 - refl, 3)
+        ior = float(rng.choice([1.0, 1.33, 1.5, 2.4]))
+        if kind == 0:
+            scene.append(_torus(c, rng.normal(size=3), rng.uniform(0.3, 0.9), rng.uniform(0.05, 0.3), col, refl, transp, ior))
+        else:
+            scene.append(_sphere(c, rng.uniform(0.2, 1.1), col, refl, transp, ior))
+    cam = Camera(eye=(_f32(rng.uniform(-3, 3)), _f32(rng.uniform(-0.5, 3)), _f32(rng.uniform(0, 4))),
+                 yaw=_f32(rng.uniform(-120, -60)), pitch=_f32(rng.uniform(-35, 15)),
+                 focal_length=_f32(rng.uniform(0.8, 3.0)),
+                 light_pos=(_f32(rng.uniform(-4, 4)), _f32(rng.uniform(1, 6)), _f32(rng.uniform(-3, 3))))
+    opts = dict(max_depth=int(rng.integers(1, 10)), stack_size=int(rng.integers(1, 9)), shadow_hops=int(rng.integers(0, 5)))
+    return scene, cam, opts

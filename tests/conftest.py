@@ -45,6 +45,8 @@ def scene_for(name):
         return rt355.mixed_scene(200)
     if name.startswith("empty"):
         return []
+    if name.startswith("random_"):
+        return rt355.random_scene(int(name.split("_")[1]))[0]
     return rt355.default_scene()
 
 

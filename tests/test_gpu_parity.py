@@ -219,3 +219,19 @@ def test_4k_headline_properties(gpu_rt):
     assert sha(img) == meta["sha256_rgba8"]
     t = gpu_rt.timing()
     assert t["kernel_ms"] > 0 and t["pending_cap"] == 3
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
+    scene, cam, o = gpu_rt.random_scene(seed)
+    n = len(scene)
+    w, h = 160, 120
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, **o)["f32"]
+    assert f32_identical(f32, ref), f"seed {seed}: n={n} {o}"
+    img = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, **o)
+    ref8 = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, **o)["rgba8"]
+    assert np.array_equal(img, ref8)
+    ev = gpu_rt.count_events(scene, cam, w, h, **o)
+    ref_ev = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_events=True, **o)["events"]
+    assert np.array_equal(ev, ref_ev)
