@@ -59,7 +59,10 @@ enum {
                                          shader's as executed by llvmpipe                           */
     RT_FLAG_NEWTON_POLISH = 1u << 1,  /* two Newton steps on the selected torus root               */
     RT_FLAG_BOTTOM_UP     = 1u << 2,  /* rows in GL order (row 0 = bottom); default row 0 = top     */
-    RT_FLAG_OUT_F32       = 1u << 3   /* write float RGBA (unclamped, alpha 1) instead of RGBA8     */
+    RT_FLAG_OUT_F32       = 1u << 3,  /* write float RGBA (unclamped, alpha 1) instead of RGBA8     */
+    RT_FLAG_NO_ACCEL      = 1u << 4   /* always run the plain per-object loop of the reference, also
+                                         on large scenes (the uniform-grid traversal used there
+                                         returns the same hits; this flag exists to verify that)   */
 };
 
 /* The uniforms of fragment_shader.glsl:12-15 as main.py:277-280 sets them, plus the

@@ -11,7 +11,8 @@ Public surface (mirrors what the reference host owns, main.py:96-132 and :244-30
 """
 from .camera import Camera, CameraController, camera_to_world, DEFAULT_LIGHT_POS
 from .scenes import (default_scene, default_camera, tori_stress_scene, tori_stress_camera,
-                     spheres_deep_scene, spheres_deep_camera, mixed_scene, mixed_camera, random_scene)
+                     spheres_deep_scene, spheres_deep_camera, mixed_scene, mixed_camera, random_scene,
+                     random_large_scene, sphere_row_scene)
 
 from . import api
 from .api import (render, render_rgba, set_scene, init, shutdown, timing, count_events, capture_segment,
@@ -21,4 +22,5 @@ __all__ = ["api", "render", "render_rgba", "set_scene", "init", "shutdown", "tim
            "capture_segment", "frame_flops", "event_table", "load_library", "RtError",
            "Camera", "CameraController", "camera_to_world", "DEFAULT_LIGHT_POS",
            "default_scene", "default_camera", "tori_stress_scene", "tori_stress_camera",
-           "spheres_deep_scene", "spheres_deep_camera", "mixed_scene", "mixed_camera", "random_scene"]
+           "spheres_deep_scene", "spheres_deep_camera", "mixed_scene", "mixed_camera", "random_scene",
+           "random_large_scene", "sphere_row_scene"]

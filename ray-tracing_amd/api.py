@@ -26,6 +26,7 @@ FLAG_FAST_MATH = 1 << 0
 FLAG_NEWTON_POLISH = 1 << 1
 FLAG_BOTTOM_UP = 1 << 2
 FLAG_OUT_F32 = 1 << 3
+FLAG_NO_ACCEL = 1 << 4
 
 
 class RtError(RuntimeError):
@@ -168,9 +169,10 @@ def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_g
     return p
 
 
-def _flags(fast_math, newton_polish, bottom_up, out_f32):
+def _flags(fast_math, newton_polish, bottom_up, out_f32, no_accel=False):
     return ((FLAG_FAST_MATH if fast_math else 0) | (FLAG_NEWTON_POLISH if newton_polish else 0) |
-            (FLAG_BOTTOM_UP if bottom_up else 0) | (FLAG_OUT_F32 if out_f32 else 0))
+            (FLAG_BOTTOM_UP if bottom_up else 0) | (FLAG_OUT_F32 if out_f32 else 0) |
+            (FLAG_NO_ACCEL if no_accel else 0))
 
 
 def set_scene(scene):
@@ -180,14 +182,15 @@ def set_scene(scene):
 
 
 def render_rgba(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
-                fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1):
+                fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
+                no_accel=False):
     """Render and return (rows, w, 4): uint8 RGBA as the reference's RGBA8 back buffer would
     hold it (main.py:303), or float32 unclamped colour with out_f32.  Row 0 is the TOP row
     unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands."""
     L = _ensure_init()
     arr = pack_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
-                    spp_grid=spp_grid, flags=_flags(fast_math, newton_polish, bottom_up, out_f32),
+                    spp_grid=spp_grid, flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel),
                     part=part, nparts=nparts)
     nbytes = L.rt_output_bytes(ctypes.addressof(p))
     bpp = 16 if out_f32 else 4

@@ -7,10 +7,12 @@
 // per-object values are the ones the reference shader computes per ray.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -131,7 +133,127 @@ KParams make_kparams(const rt_params *p)
     for (int i = 0; i < 16; ++i)
         k.sample_off[i] = i < p->spp_grid ? (float)(((double)i + 0.5) / (double)p->spp_grid - 0.5) : 0.0f;
     k.scene = g.layout;
+    k.use_hierarchy = (g.layout.n1 > 0 && !(p->flags & RT_FLAG_NO_ACCEL)) ? 1 : 0;
     return k;
+}
+
+// Scenes with at least this many objects get the sphere hierarchy; below it the packed
+// per-object loop is cheaper than a traversal.  RT_HIERARCHY_MIN overrides (experiments).
+int hierarchy_min_objects()
+{
+    static const int v = [] {
+        const char *e = getenv("RT_HIERARCHY_MIN");
+        return e ? atoi(e) : 40;
+    }();
+    return v;
+}
+
+// Effective bounding radius of an object: the square root of the binary32 value br*br the
+// reference's bounding test uses (fragment_shader.glsl:391-402).
+double bound_radius(const rt_object &o)
+{
+    float br = o.type == 1 ? o.radius : o.major_radius + o.minor_radius;
+    float br2 = br * br;
+    return std::sqrt((double)br2);
+}
+
+// Spatial order for the hierarchy: recursive median split along the longest axis of the
+// centres' bounding box; split points fall on multiples of RT_LEAF (of RT_LEAF*RT_FAN higher
+// up) so that consecutive leaf nodes, and consecutive groups of RT_FAN of them, are subtrees.
+void spatial_order(const rt_object *objs, int *idx, int lo, int hi)
+{
+    int cnt = hi - lo;
+    if (cnt <= RT_LEAF) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = lo; k < hi; ++k)
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], objs[idx[k]].center[a]);
+            mx[a] = std::max(mx[a], objs[idx[k]].center[a]);
+        }
+    int axis = 0;
+    if (mx[1] - mn[1] > mx[axis] - mn[axis]) axis = 1;
+    if (mx[2] - mn[2] > mx[axis] - mn[axis]) axis = 2;
+    int unit = cnt > RT_LEAF * RT_FAN ? RT_LEAF * RT_FAN : RT_LEAF;
+    int half = ((cnt / 2 + unit - 1) / unit) * unit;
+    if (half >= cnt) half = cnt - unit > 0 ? cnt - unit : cnt / 2;
+    int mid = lo + half;
+    std::nth_element(idx + lo, idx + mid, idx + hi, [&](int x, int y) {
+        float cx = objs[x].center[axis], cy = objs[y].center[axis];
+        return cx < cy || (cx == cy && x < y);
+    });
+    spatial_order(objs, idx, lo, mid);
+    spatial_order(objs, idx, mid, hi);
+}
+
+// Bounding sphere {cx, cy, cz, R} of the bounding spheres of objects idx[lo..hi): centre =
+// centre of their axis-aligned box, R = max(|c_i - centre| + br_i) rounded up.
+void node_sphere(const rt_object *objs, const int *idx, int lo, int hi, float out[4])
+{
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int k = lo; k < hi; ++k) {
+        const rt_object &o = objs[idx[k]];
+        double br = bound_radius(o);
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], (double)o.center[a] - br);
+            mx[a] = std::max(mx[a], (double)o.center[a] + br);
+        }
+    }
+    float c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (float)(0.5 * (mn[a] + mx[a]));
+    double R = 0.0;
+    for (int k = lo; k < hi; ++k) {
+        const rt_object &o = objs[idx[k]];
+        double dx = (double)o.center[0] - c[0], dy = (double)o.center[1] - c[1], dz = (double)o.center[2] - c[2];
+        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + bound_radius(o));
+    }
+    float Rf = (float)(R * (1.0 + 1e-6));
+    if ((double)Rf < R) Rf = std::nextafter(Rf, INFINITY);
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = Rf;
+}
+
+// Fills the hierarchy sections of the blob.
+void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
+{
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    spatial_order(objs, idx.data(), 0, n);
+    auto put_node = [&](int off, int j, const float s[4]) {
+        float *r = blob + off + 8 * (j >> 1) + (j & 1);
+        r[0] = s[0]; r[2] = s[1]; r[4] = s[2]; r[6] = s[3];
+    };
+    float s[4], all[4];
+    node_sphere(objs, idx.data(), 0, n, all);
+    double reach = all[3];
+    auto cover = [&](const float nd[4]) {    // the scene sphere must contain the node spheres too
+        double dx = (double)nd[0] - all[0], dy = (double)nd[1] - all[1], dz = (double)nd[2] - all[2];
+        reach = std::max(reach, (std::sqrt(dx * dx + dy * dy + dz * dz) + nd[3]) * (1.0 + 1e-6));
+    };
+    for (int j = 0; j < L.n2; ++j) {
+        int lo = j * RT_LEAF * RT_FAN, hi = std::min(n, lo + RT_LEAF * RT_FAN);
+        node_sphere(objs, idx.data(), lo, hi, s);
+        put_node(L.off_top, j, s);
+        cover(s);
+    }
+    for (int j = 0; j < L.n1; ++j) {
+        int lo = j * RT_LEAF, hi = std::min(n, lo + RT_LEAF);
+        node_sphere(objs, idx.data(), lo, hi, s);
+        put_node(L.off_leaf, j, s);
+        cover(s);
+    }
+    L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
+    L.hR = std::nextafter((float)reach, INFINITY);
+    uint16_t *slot_id = reinterpret_cast<uint16_t *>(blob + L.off_slot_id);
+    for (int sl = 0; sl < L.n1 * RT_LEAF; ++sl) {
+        float *r = blob + L.off_member + 8 * (sl >> 1) + (sl & 1);
+        if (sl < n) {
+            const float *src = blob + 8 * (idx[sl] >> 1) + (idx[sl] & 1);   // the object's own bound record
+            r[0] = src[0]; r[2] = src[2]; r[4] = src[4]; r[6] = src[6];
+            slot_id[sl] = (uint16_t)idx[sl];
+        } else {
+            r[0] = r[2] = r[4] = 0.0f; r[6] = -INFINITY;
+            slot_id[sl] = 0;
+        }
+    }
 }
 
 const char *const k_event_names[EV_COUNT] = {
@@ -212,7 +334,7 @@ int rt_set_scene(const rt_object *objs, int n)
             if (!std::isfinite(f[k])) return fail(RT_E_SCENE, "object %d: field %d is not finite", i, k + 1);
         if (o.type == 2) ntori++;
     }
-    SceneLayout L = scene_layout(n, ntori);
+    SceneLayout L = scene_layout(n, ntori, n >= hierarchy_min_objects() && n > RT_LEAF);
     std::vector<float> blob((size_t)L.total_dwords + 4, 0.0f);
     int *kind = reinterpret_cast<int *>(blob.data() + L.off_kind);
     int slot = 0;
@@ -250,6 +372,7 @@ int rt_set_scene(const rt_object *objs, int n)
         t[12] = (4.0f * R) * R; t[13] = (8.0f * R) * R;
         slot++;
     }
+    if (L.n1 > 0) build_hierarchy(objs, n, L, blob.data());
     size_t bytes = (size_t)L.total_dwords * sizeof(float);
     if (bytes < 16) bytes = 16;
     if (bytes > g.d_scene_cap) {

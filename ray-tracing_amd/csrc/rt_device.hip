@@ -379,6 +379,22 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
     if (hit && t < bt) { bt = t; bid = i; }
 }
 
+// intersect_plane (:107-123): y = -1, two-sided; tested after all objects (:428-433).
+template <bool DEBUG>
+DEV void offer_plane(float oy, float dy, int n, float &bt, int &bid, const Counters<DEBUG> &cnt)
+{
+    CNT(EV_PLANE_CALL);
+    bool ok = __builtin_fabsf(dy) > 0.0001f;
+    if (ok) {
+        CNT(EV_PLANE_T);
+        float t = rt_div(-1.0f - oy, dy);
+        if (t > 0.001f) {
+            CNT(EV_PLANE_HIT);
+            if (t < bt) { bt = t; bid = n; }
+        }
+    }
+}
+
 // Closest hit as (t, id): id -1 none, 0..n-1 scene object, n ground plane.
 // The bounding test (:399-402) runs on two objects per instruction with packed FP32 math
 // (v_pk_add/v_pk_mul: each half is an ordinary correctly rounded binary32 operation, so
@@ -424,17 +440,147 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
         if (!(disc.y < 0.0f))
             test_candidate<DEBUG>(lds, L, polish, 2 * j + 1, a, ocx.y, ocy.y, ocz.y, b.y, c.y, disc.y, dx, dy, dz, bt, bid, cnt);
     }
-    // intersect_plane (:107-123): y = -1, two-sided
-    CNT(EV_PLANE_CALL);
-    bool ok = __builtin_fabsf(dy) > 0.0001f;
-    if (ok) {
-        CNT(EV_PLANE_T);
-        float t = rt_div(-1.0f - oy, dy);
-        if (t > 0.001f) {
-            CNT(EV_PLANE_HIT);
-            if (t < bt) { bt = t; bid = n; }
+    offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
+    best_t = bt; best_id = bid;
+}
+
+// ------------------------------------------------------------------ trace through the sphere hierarchy
+//
+// The reference's loop (:386-426) only ever acts on objects whose bounding test passes
+// (disc >= 0); for those, what it does depends on the order (the t_bound > closest.t skip and
+// "first index wins").  trace_hierarchy therefore (1) finds exactly the set of objects whose
+// bounding test passes, by walking two levels of enclosing spheres and running the reference's
+// own bounding arithmetic on the members of the leaf nodes it reaches, and (2) replays the
+// reference's loop body over that set in ascending object index.  Step 2 is the reference
+// algorithm with the iterations it would have culled left out, so the result is the same
+// (t, id) for every ray, whatever the enclosing spheres look like -- provided step 1 never
+// drops an object that passes.  A node (centre g, radius R) is kept when
+//     disc_node + slack >= 0     (or the comparison is unordered: NaN/inf keep everything)
+// where disc_node is the bounding discriminant of the sphere (g, R + grow), with
+//     reach = |o - scene centre| + scene radius  (>= |oc| + radius for every object and node),
+//     grow  = sf * reach,  sf^2 = 2.5e-6 + 1.1 |dot(d,d) - 1|,
+//     slack = sf^2 (reach^2 + (reach + grow)^2).
+// Why that is enough: a member whose binary32 disc is >= 0 has its centre within
+// br + sqrt(E) of the ray's line, where E <= (17u + |dot(d,d) - 1|) |oc|^2 + 2u br^2
+// (u = 2^-24) bounds the rounding of the member test plus the direction's deviation from unit
+// length, so sqrt(E) <= grow; the member's sphere lies inside the node's, so the line passes
+// within R + grow of g, i.e. the exact node discriminant is >= 0, and the binary32 one
+// differs from it by less than sf^2 (|oc_node|^2 + (R + grow)^2) <= slack.
+//
+// The candidates are queued per ray in LDS as 16-bit object indices; a ray that collects
+// more than RT_QUEUE of them walks all objects in step 2 instead (same result, slower).
+DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v2f DZ, float grow, float slack,
+                   bool &keep0, bool &keep1)
+{
+    v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, R = {B.z, B.w};
+    v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
+    v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+    v2f G = {grow, grow}, S = {slack, slack};
+    v2f Re = R + G;
+    v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
+    v2f disc = b * b - (oc2 - Re * Re);
+    v2f s = disc + S;
+    keep0 = !(s.x < 0.0f);
+    keep1 = !(s.y < 0.0f);
+}
+
+template <bool DEBUG>
+DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L, int polish, unsigned short *queue,
+                         float ox, float oy, float oz, float dx, float dy, float dz,
+                         float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+{
+    const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
+    const int n = L.n, n1 = L.n1, n2 = L.n2;
+    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+    // growth and slack of the node test, once per ray: every object and node lies inside the
+    // scene sphere (L.hc, L.hR), so |oc| + R <= reach = |o - hc| + hR for all of them
+    float sf2 = 2.5e-6f + 1.1f * __builtin_fabsf(a - 1.0f);
+    const float sf = __builtin_amdgcn_sqrtf(sf2) * 1.02f;
+    const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
+    const float reach = (__builtin_amdgcn_sqrtf((qz * qz + qy * qy) + qx * qx) + L.hR) * 1.0001f;
+    const float grow = sf * reach;
+    const float slack = (sf2 * 1.05f) * (reach * reach + (reach + grow) * (reach + grow)) + 1e-30f;
+    // hl = the hierarchy sections in LDS, starting at the top nodes
+    const float4 *top = reinterpret_cast<const float4 *>(hl);
+    const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
+    const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
+    const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
+
+    // ---- step 1: collect the objects whose bounding test passes
+    int count = 0;
+    for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
+        bool kt[2];
+        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, kt[0], kt[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tn = 2 * j + h;
+            if (!(kt[h] && tn < n2)) continue;
+            const int first = tn * RT_FAN;                       // first leaf node of this top node
+            const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
+            for (int kk = 0; kk < ((nleaf + 1) >> 1); ++kk) {
+                bool kl[2];
+                const int lp = (first >> 1) + kk;
+                node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, kl[0], kl[1]);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int leaf = first + 2 * kk + h2;
+                    if (!(kl[h2] && leaf < n1)) continue;
+                    for (int m = 0; m < RT_LEAF / 2; ++m) {
+                        const int mp = leaf * (RT_LEAF / 2) + m;
+                        const float4 A = memb[2 * mp], B = memb[2 * mp + 1];
+                        // the reference's bounding test (:399-402), operation for operation
+                        v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
+                        v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
+                        v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                        v2f c = oc2 - br2;
+                        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
+                        v2f disc = b * b - c;
+                        if (!(disc.x < 0.0f)) {
+                            if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp];
+                            count++;
+                        }
+                        if (!(disc.y < 0.0f)) {
+                            if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp + 1];
+                            count++;
+                        }
+                    }
+                }
+            }
         }
     }
+
+    // ---- step 2: the reference's loop body over the candidates in ascending index
+    CNT(EV_TRACE);
+    float bt = 1e30f;
+    int bid = -1;
+    const bool walk_all = count > RT_QUEUE;
+    int last = -1;
+    for (;;) {
+        int i;
+        if (!walk_all) {
+            int mnext = 0x7fffffff;
+            for (int q = 0; q < count; ++q) {
+                int v = queue[q * 256];
+                mnext = (v > last && v < mnext) ? v : mnext;
+            }
+            if (mnext == 0x7fffffff) break;
+            i = mnext;
+        } else {
+            i = last + 1;
+            if (i >= n) break;
+        }
+        last = i;
+        const float *rec = sc + 8 * (i >> 1) + (i & 1);
+        float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
+        float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+        float c = oc2 - rec[6];
+        float b = (ocz * dz + ocy * dy) + ocx * dx;
+        float disc = b * b - c;
+        if (disc < 0.0f) continue;
+        test_candidate<DEBUG>(sc, L, polish, i, a, ocx, ocy, ocz, b, c, disc, dx, dy, dz, bt, bid, cnt);
+    }
+    offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
     best_t = bt; best_id = bid;
 }
 
@@ -453,6 +599,9 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2
 #endif
+#ifndef RT_WAVES_PER_EU_HIER
+#define RT_WAVES_PER_EU_HIER 3
+#endif
 #ifndef RT_WAVES_PER_EU_LDSP
 #define RT_WAVES_PER_EU_LDSP 4
 #endif
@@ -460,21 +609,30 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // column per lane) instead of registers; used where that buys a wave of occupancy.
 // MULTI: more than one sample per pixel (sample loop + accumulators); the single-sample
 // kernel carries neither.
-template <int CAP, bool DEBUG, bool LDSP, bool MULTI>
-__global__ __launch_bounds__(256, LDSP ? RT_WAVES_PER_EU_LDSP : RT_WAVES_PER_EU)
+// HIER: trace through the sphere hierarchy (large scenes); the candidate queue follows the
+// scene in LDS.
+template <int CAP, bool DEBUG, bool LDSP, bool MULTI, bool HIER>
+__global__ __launch_bounds__(256, LDSP ? RT_WAVES_PER_EU_LDSP : (HIER && CAP <= 7) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
     extern __shared__ float4 lds4[];
     float *lds = reinterpret_cast<float *>(lds4);
     const SceneLayout L = kp.scene;
+    // HIER keeps only the hierarchy sections in LDS (they are what every ray reads many
+    // times); bound records, materials and torus frames are read a few times per ray and
+    // come from global memory through the caches, which leaves LDS room for several
+    // workgroups per CU however large the scene is.
+    const int lds_first = HIER ? L.off_top : 0;
+    const int lds_dwords = L.total_dwords - lds_first;
     {
-        const float4 *src = reinterpret_cast<const float4 *>(scene);
-        const int nq = L.total_dwords >> 2;
+        const float4 *src = reinterpret_cast<const float4 *>(scene + lds_first);
+        const int nq = lds_dwords >> 2;
         for (int i = threadIdx.x; i < nq; i += 256) lds4[i] = src[i];
     }
+    const float *sc = HIER ? scene : lds;       // bound records, materials, torus frames, kinds
     Counters<DEBUG> cnt;
-    cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + L.total_dwords);
+    cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + lds_dwords);
     if (DEBUG) { if (threadIdx.x < EV_COUNT) cnt.lds_ev[threadIdx.x] = 0u; }
     __syncthreads();
 
@@ -508,7 +666,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         pend.tx[k] = pend.ty[k] = pend.tz[k] = 0; pend.ior[k] = 1; pend.depth[k] = 0;
     }
     // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
-    float *pend_lds = lds + ((L.total_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
+    float *pend_lds = lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
+    // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
+    unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3)) + threadIdx.x;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit
     float hx = 0, hy = 0, hz = 0;            // hit position
@@ -545,7 +705,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 
     while (active) {
         float t; int id;
-        trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
+        if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
+        else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
 
         bool spawn = false;     // this lane finished shading a hit: spawn children
         bool pop = false;       // this lane needs its next ray from the pending slots
@@ -578,19 +739,19 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     mr = mg = mb = col; m_refl = 0.05f; m_transp = 0.0f; h_ior = 1.0f;
                     h_r0 = 0.0f; h_eta_in = 1.0f;         // ((1-1)/(1+1))^2 and 1/1
                 } else {
-                    const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
+                    const float4 *mat = reinterpret_cast<const float4 *>(sc + L.off_material) + 2 * id;
                     float4 m0 = mat[0], m1 = mat[1];
                     mr = m0.x; mg = m0.y; mb = m0.z; m_refl = m0.w; m_transp = m1.x; h_ior = m1.y;
                     h_r0 = m1.z; h_eta_in = m1.w;
                     float qx, qy, qz;
-                    object_centre(lds, id, qx, qy, qz);
-                    int kd = reinterpret_cast<const int *>(lds + L.off_kind)[id];
+                    object_centre(sc, id, qx, qy, qz);
+                    int kd = reinterpret_cast<const int *>(sc + L.off_kind)[id];
                     if (kd < 0) {
                         float vx = hx - qx, vy = hy - qy, vz = hz - qz;
                         float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
                         nx = vx * rs; ny = vy * rs; nz = vz * rs;
                     } else {
-                        TorusFrame f = load_torus(lds, L.off_torus, kd);
+                        TorusFrame f = load_torus(sc, L.off_torus, kd);
                         float ocx = ox - qx, ocy = oy - qy, ocz = oz - qz;
                         float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
                         float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
@@ -666,7 +827,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         // the ground is opaque (:128): whichever checker colour, colour * 0 = +0
                         cr = cg = cb = 0.9f; ctr = 0.0f;
                     } else {
-                        const float4 *mat = reinterpret_cast<const float4 *>(lds + L.off_material) + 2 * id;
+                        const float4 *mat = reinterpret_cast<const float4 *>(sc + L.off_material) + 2 * id;
                         float4 m0 = mat[0];
                         cr = m0.x; cg = m0.y; cb = m0.z; ctr = mat[1].x;
                     }
@@ -835,13 +996,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, bool LDSP, bool MULTI>
+template <int CAP, bool DEBUG, bool LDSP, bool MULTI, bool HIER>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
-    auto kfn = rt_kernel<CAP, DEBUG, LDSP, MULTI>;
-    size_t lds = (size_t)kp.scene.total_dwords * 4 + (DEBUG ? EV_COUNT * 4 : 0);
+    static_assert(!(LDSP && HIER), "the LDS pending slots and the candidate queue share one region");
+    auto kfn = rt_kernel<CAP, DEBUG, LDSP, MULTI, HIER>;
+    size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
+    if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     if (const char *pad = getenv("RT_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static bool attr_set = false;
     if (!attr_set) {
@@ -879,8 +1043,16 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
     const bool multi = kp.spp > 1;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
-    (multi ? launch_variant<CAP_, false, LDSP_, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)       \
-           : launch_variant<CAP_, false, LDSP_, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+    (multi ? launch_variant<CAP_, false, LDSP_, true, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
+           : launch_variant<CAP_, false, LDSP_, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+#define RT_LAUNCH_HIER(CAP_)                                                                                \
+    (multi ? launch_variant<CAP_, false, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
+           : launch_variant<CAP_, false, false, false, true>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+    if (kp.use_hierarchy && kp.scene.n1 > 0) {
+        if (need <= 3) return RT_LAUNCH_HIER(3);
+        if (need <= 7) return RT_LAUNCH_HIER(7);
+        return RT_LAUNCH_HIER(16);
+    }
     if (need <= 3) {
         // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
         // CU next to a small scene, and frees the registers for a fourth wave per SIMD
@@ -891,13 +1063,14 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     if (need <= 7) return RT_LAUNCH(7, false);
     return RT_LAUNCH(16, false);
 #undef RT_LAUNCH
+#undef RT_LAUNCH_HIER
 }
 
 int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events, float *d_capture,
                  void *stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return launch_variant<16, true, false, true>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
+    return launch_variant<16, true, false, true, false>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
 }
 
 }  // namespace RT_NS

@@ -12,6 +12,14 @@
 //   [.., + 8n)           material[i] = { r, g, b, reflectivity } { transparency, ior, r0, 1/ior }: r0 = ((1-ior)/(1+ior))^2
 //   [.., + 16*nt)        torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
 //   [.., + n)            kind[i]     = -1 for a sphere, torus slot s >= 0 for a torus
+// Large scenes add a two-level hierarchy of bounding spheres over the objects' bounding
+// spheres (objects sorted into spatial order; a leaf node holds RT_LEAF consecutive slots, a
+// top node RT_FAN consecutive leaf nodes):
+//   [.., + 8*ceil(n2/2)) top[j]      = { cx0 cx1 cy0 cy1 } { cz0 cz1 R0 R1 }: nodes 2j, 2j+1
+//   [.., + 8*ceil(n1/2)) leaf[j]     = same record, leaf nodes 2j, 2j+1
+//   [.., + 8*n1*RT_LEAF/2) member[s] = bound records (as bound[]) of the objects in slot order;
+//                                      empty slots carry br = -inf
+//   [.., + n1*RT_LEAF/2) slot_id[s]  = object index of slot s, 16 bits each
 // Keeping only the 16 bytes per object of the bound record in the per-object hot loop and
 // everything else behind the bound test is what makes 1024 objects fit in LDS next to
 // several workgroups.
@@ -20,10 +28,17 @@ struct SceneLayout {
     int off_material;   // dword offsets
     int off_torus;
     int off_kind;
+    int n1, n2;         // leaf / top nodes of the sphere hierarchy (0: none)
+    int off_top, off_leaf, off_member, off_slot_id;
+    float hc[3], hR;    // sphere that contains every object's bounding sphere and every node
     int total_dwords;   // padded to a multiple of 4
 };
 
-static inline SceneLayout scene_layout(int n, int ntori)
+#define RT_LEAF 8        // object slots per leaf node (even)
+#define RT_FAN 8         // leaf nodes per top node (even)
+#define RT_QUEUE 32      // per-ray candidate queue entries (16 bits each, in LDS)
+
+static inline SceneLayout scene_layout(int n, int ntori, bool hierarchy)
 {
     SceneLayout L;
     L.n = n; L.ntori = ntori;
@@ -31,7 +46,20 @@ static inline SceneLayout scene_layout(int n, int ntori)
     L.off_material = 8 * np;
     L.off_torus = L.off_material + 8 * n;
     L.off_kind = L.off_torus + 16 * ntori;
-    L.total_dwords = (L.off_kind + n + 3) & ~3;
+    int end = (L.off_kind + n + 3) & ~3;
+    L.n1 = L.n2 = 0;
+    L.hc[0] = L.hc[1] = L.hc[2] = 0.0f; L.hR = 0.0f;
+    L.off_top = L.off_leaf = L.off_member = L.off_slot_id = end;
+    if (hierarchy) {
+        L.n1 = (n + RT_LEAF - 1) / RT_LEAF;
+        L.n2 = (L.n1 + RT_FAN - 1) / RT_FAN;
+        L.off_top = end;
+        L.off_leaf = L.off_top + 8 * ((L.n2 + 1) / 2);
+        L.off_member = L.off_leaf + 8 * ((L.n1 + 1) / 2);
+        L.off_slot_id = L.off_member + 8 * (L.n1 * RT_LEAF / 2);
+        end = (L.off_slot_id + L.n1 * RT_LEAF / 2 + 3) & ~3;
+    }
+    L.total_dwords = end;
     return L;
 }
 
@@ -50,6 +78,7 @@ struct KParams {
     int capture_seg;        // debug flavour only
     float sample_off[16];   // (i + 0.5)/spp - 0.5 for i < spp, rounded to binary32
     SceneLayout scene;
+    int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
 };
 
 // ---- work events (same classes, same weights as the shader-source FLOP convention) ----

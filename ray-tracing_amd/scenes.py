@@ -152,3 +152,56 @@ def random_scene(seed: int):
                  light_pos=(_f32(rng.uniform(-4, 4)), _f32(rng.uniform(1, 6)), _f32(rng.uniform(-3, 3))))
     opts = dict(max_depth=int(rng.integers(1, 10)), stack_size=int(rng.integers(1, 9)), shadow_hops=int(rng.integers(0, 5)))
     return scene, cam, opts
+
+
+def random_large_scene(seed: int):
+    """Large random scene (100-700 objects) built to stress a spatial hierarchy: clusters of very
+    different density, a few huge spheres that contain many others, objects far from the rest,
+    duplicated centres (equal hit distances decided by index), tori of all sizes; the camera is
+    inside the cloud, far outside it, or looking along a row.  Returns (scene, camera, opts)."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(100, 700))
+    scene = []
+    ncl = int(rng.integers(1, 6))
+    centres = rng.uniform([-8, 0, -25], [8, 6, -2], size=(ncl, 3))
+    spread = rng.uniform(0.3, 6.0, size=ncl)
+    while len(scene) < n:
+        k = int(rng.integers(0, ncl))
+        c = centres[k] + rng.normal(size=3) * spread[k]
+        u = rng.uniform()
+        col = rng.uniform(0.1, 1.0, size=3)
+        refl = float(rng.choice([0.0, 0.05, 0.5, 0.9]))
+        transp = float(rng.choice([0.0, 0.0, 0.0, 0.7]))
+        if refl + transp > 1.0:
+            transp = 0.0
+        ior = float(rng.choice([1.0, 1.33, 1.5]))
+        if u < 0.02:
+            scene.append(_sphere(c, rng.uniform(3.0, 9.0), col, 0.05, 0.85, 1.1))       # huge glass shell
+        elif u < 0.05:
+            scene.append(_sphere(c + rng.normal(size=3) * 60.0, rng.uniform(0.5, 4.0), col, refl, 0.0, ior))  # outlier
+        elif u < 0.10 and scene:
+            twin = dict(scene[int(rng.integers(0, len(scene)))])                        # exact duplicate
+            scene.append(twin)
+        elif u < 0.35:
+            scene.append(_torus(c, rng.normal(size=3), rng.uniform(0.1, 1.5), rng.uniform(0.02, 0.4), col, refl, transp, ior))
+        else:
+            scene.append(_sphere(c, rng.uniform(0.05, 0.9), col, refl, transp, ior))
+    mode = seed % 3
+    if mode == 0:       # inside the cloud
+        eye = centres[0] + rng.normal(size=3) * 0.5
+        cam = Camera(eye=_vec(eye), yaw=_f32(rng.uniform(-180, 180)), pitch=_f32(rng.uniform(-30, 30)),
+                     focal_length=_f32(rng.uniform(0.7, 2.0)))
+    elif mode == 1:     # far away, long lens
+        cam = Camera(eye=(_f32(rng.uniform(-20, 20)), _f32(rng.uniform(5, 40)), _f32(rng.uniform(150, 400))),
+                     yaw=-90.0, pitch=_f32(rng.uniform(-8, -2)), focal_length=_f32(rng.uniform(8.0, 20.0)))
+    else:
+        cam = Camera(eye=(_f32(rng.uniform(-3, 3)), _f32(rng.uniform(0.5, 4)), _f32(rng.uniform(2, 8))),
+                     yaw=_f32(rng.uniform(-110, -70)), pitch=_f32(rng.uniform(-20, 5)),
+                     focal_length=_f32(rng.uniform(1.0, 3.0)))
+    opts = dict(max_depth=int(rng.integers(2, 9)), stack_size=int(rng.integers(1, 9)), shadow_hops=int(rng.integers(0, 4)))
+    return scene, cam, opts
+
+
+def sphere_row_scene(n: int = 120):
+    """n equal glass spheres in a row along -z: a ray down the row passes every bounding sphere."""
+    return [_sphere([0.0, 0.5, -2.0 - 1.5 * i], 0.6, [0.9, 0.9, 1.0], 0.05, 0.9, 1.02) for i in range(n)]

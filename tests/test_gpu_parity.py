@@ -235,3 +235,51 @@ def test_random_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
     ev = gpu_rt.count_events(scene, cam, w, h, **o)
     ref_ev = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_events=True, **o)["events"]
     assert np.array_equal(ev, ref_ev)
+
+
+# ---- the sphere hierarchy used on large scenes returns the per-object loop's hits, bit for bit
+
+def _accel_vs_plain(gpu_rt, scene, cam, w, h, **o):
+    fast = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    lds_fast = gpu_rt.timing()["lds_bytes"]
+    plain = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, no_accel=True, **o)
+    # two different kernels ran: the hierarchy variant keeps the node records and a 16 KB
+    # candidate queue in LDS, the per-object loop the whole scene
+    assert lds_fast != gpu_rt.timing()["lds_bytes"]
+    return fast, plain
+
+
+@pytest.mark.parametrize("seed", range(9))
+def test_hierarchy_equals_per_object_loop_random_large(gpu_rt, orc, seed):
+    scene, cam, o = gpu_rt.random_large_scene(seed)
+    w, h = 240, 136
+    fast, plain = _accel_vs_plain(gpu_rt, scene, cam, w, h, **o)
+    assert f32_identical(fast, plain), f"seed {seed}: n={len(scene)} {o}"
+    if seed < 4:
+        ws, hs = 96, 54
+        small = gpu_rt.render_rgba(scene, cam, ws, hs, bottom_up=True, out_f32=True, **o)
+        ref = orc.render(scene, cam.matrix(), cam.focal_length, ws, hs, light=cam.light_pos, want_f32=True, **o)["f32"]
+        assert f32_identical(small, ref), f"seed {seed}: n={len(scene)} {o}"
+
+
+def test_hierarchy_equals_per_object_loop_named_scenes(gpu_rt):
+    for scene, cam, w, h, o in [
+        (gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 480, 270, dict(max_depth=16, stack_size=16, shadow_hops=4)),
+        (gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera(), 480, 270, dict(max_depth=8, stack_size=8, shadow_hops=2)),
+        (gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera(), 160, 90, dict(max_depth=4, stack_size=3, shadow_hops=2, spp_grid=2)),
+        (gpu_rt.mixed_scene(333, seed=7), gpu_rt.mixed_camera(), 320, 180, dict(max_depth=5, stack_size=2, shadow_hops=1)),
+    ]:
+        fast, plain = _accel_vs_plain(gpu_rt, scene, cam, w, h, **o)
+        assert f32_identical(fast, plain), f"n={len(scene)} {o}"
+
+
+def test_hierarchy_candidate_queue_overflow(gpu_rt, orc):
+    """A ray down a row of 120 spheres passes more bounding spheres than the candidate queue
+    holds; such rays walk all objects and must still agree."""
+    scene = gpu_rt.sphere_row_scene(120)
+    cam = gpu_rt.Camera(eye=(0.0, 0.5, 3.0), yaw=-90.0, pitch=0.0, focal_length=3.0)
+    o = dict(max_depth=6, stack_size=4, shadow_hops=2)
+    fast, plain = _accel_vs_plain(gpu_rt, scene, cam, 200, 120, **o)
+    assert f32_identical(fast, plain)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, 200, 120, want_f32=True, **o)["f32"]
+    assert f32_identical(fast, ref)

@@ -27,6 +27,12 @@ CONFIGS = {
     "4k_empty": dict(scene="empty", w=3840, h=2160, max_depth=8, stack_size=3, shadow_hops=2, golden=None),
     "tori64_4k": dict(scene="tori", w=3840, h=2160, max_depth=8, stack_size=3, shadow_hops=2, golden=None),
     "spheres256_4k": dict(scene="spheres", w=3840, h=2160, max_depth=16, stack_size=16, shadow_hops=4, golden=None),
+    "spheres256_1080": dict(scene="spheres", w=1920, h=1080, max_depth=16, stack_size=16, shadow_hops=4, golden=None),
+    "mixed1024_1080": dict(scene="mixed", w=1920, h=1080, max_depth=8, stack_size=8, shadow_hops=2, golden=None),
+    "mixed1024_4k_d4": dict(scene="mixed", w=3840, h=2160, max_depth=4, stack_size=3, shadow_hops=2, golden=None),
+    **{f"mixed{n}_4k_d4": dict(scene=f"mixed:{n}", w=3840, h=2160, max_depth=4, stack_size=3, shadow_hops=2, golden=None)
+       for n in (12, 16, 24, 32, 48, 64, 96, 128)},
+    "tori64_1080": dict(scene="tori", w=1920, h=1080, max_depth=8, stack_size=3, shadow_hops=2, golden=None),
     "mixed1024_8k_16spp": dict(scene="mixed", w=7680, h=4320, max_depth=8, stack_size=8, shadow_hops=2, spp_grid=4, golden=None),
 }
 
@@ -40,13 +46,18 @@ def child(args):
     which = cfg.pop("scene")
     golden = cfg.pop("golden")
     w, h = cfg.pop("w"), cfg.pop("h")
-    scene, cam = {"default": (rt355.default_scene, rt355.default_camera), "empty": (lambda: [], rt355.default_camera), "tori": (rt355.tori_stress_scene, rt355.tori_stress_camera),
+    if which.startswith("mixed:"):
+        nobj = int(which.split(":")[1])
+        which = "mixedN"
+    scene, cam = {"mixedN": (lambda: rt355.mixed_scene(nobj), rt355.mixed_camera), "default": (rt355.default_scene, rt355.default_camera), "empty": (lambda: [], rt355.default_camera), "tori": (rt355.tori_stress_scene, rt355.tori_stress_camera),
                   "spheres": (rt355.spheres_deep_scene, rt355.spheres_deep_camera),
                   "mixed": (rt355.mixed_scene, rt355.mixed_camera)}[which]
     scene, cam = scene(), cam()
     lib = rt355.init(0)
     rt355.set_scene(scene)
     flags = (rt355.api.FLAG_FAST_MATH if args.fast else 0) | rt355.api.FLAG_BOTTOM_UP
+    if args.no_accel:
+        flags |= rt355.api.FLAG_NO_ACCEL
     p = rt355.api.make_params(cam, w, h, flags=flags, **cfg)
     out = np.empty((h, w, 4), dtype=np.uint8)
     ok = None
@@ -68,6 +79,7 @@ def child(args):
     times = np.array(times[2:])
     print(json.dumps({"lib": os.path.basename(args.lib), "config": args.config, "min_ms": float(times.min()),
                       "median_ms": float(np.median(times)), "vgprs": t.vgprs, "cap": t.pending_cap, "sha_ok": ok,
+                      "sha": hashlib.sha256(out.tobytes()).hexdigest()[:16], "no_accel": bool(args.no_accel),
                       "host_roundtrip_ms": t_host.total_ms}))
 
 
@@ -79,6 +91,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--config", default="4k_d8s3")
     ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--no-accel", action="store_true")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -88,6 +101,8 @@ def main():
             cmd = [sys.executable, __file__, "--child", "--lib", os.path.abspath(lib), "--iters", str(args.iters), "--config", args.config]
             if args.fast:
                 cmd.append("--fast")
+            if args.no_accel:
+                cmd.append("--no-accel")
             res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
             line = [l for l in res.stdout.splitlines() if l.startswith("{")]
             print(line[-1] if line else f"FAILED {lib}: {res.stderr[-500:]}", flush=True)
