@@ -61,7 +61,11 @@ def main():
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_GATHER=1 (under torch.distributed.run, also with one rank) sends every frame
+    # through the RCCL gather + assemble path: a rehearsal of the N > 1 code on a one-GPU box
+    force_gather = os.environ.get("RT_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ
+    use_dist = world > 1 or force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -90,7 +94,8 @@ def main():
     def assemble(gathered, image):
         check(lib.rt_assemble_device(gathered.data_ptr(), image.data_ptr(), W, H, world, 4, sptr))
 
-    pipe = tiling.BandPipeline(H, W, 4, torch.uint8, dev, dist if world > 1 else None, render_part, assemble)
+    pipe = tiling.BandPipeline(H, W, 4, torch.uint8, dev, dist if use_dist else None, render_part, assemble,
+                               always_gather=force_gather)
     image = pipe.image
 
     def run(steps):
@@ -99,7 +104,7 @@ def main():
         pipe.flush()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,7 +118,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stream_ms = e0.elapsed_time(e1)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -135,7 +140,7 @@ def main():
         }
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not force_gather:
         full = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
                                      shadow_hops=SHADOW_HOPS, flags=flags)
         import numpy as np
@@ -176,8 +181,15 @@ def main():
             }
 
     if rank == 0:
+        if force_gather:
+            # the gathered + assembled frame must be the frame itself
+            import hashlib
+            golden = json.load(open(os.path.join(ROOT, "tests", "golden", "default_4k_d8s3.json")))
+            if not args.fast_math and args.stack_size == STACK_SIZE:
+                got = hashlib.sha256(image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
+                result["gathered_frame_sha_ok"] = got == golden["sha256_rgba8"]
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

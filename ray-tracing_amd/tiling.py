@@ -80,19 +80,24 @@ class BandPipeline:
     assemble(gathered, image)        rank 0 only: (nparts, padded_rows, w, c) -> (h, w, c)
     """
 
-    def __init__(self, height, width, channels, dtype, device, dist, render_part, assemble):
+    def __init__(self, height, width, channels, dtype, device, dist, render_part, assemble,
+                 always_gather=False):
         import torch
         self.torch, self.dist = torch, dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.h, self.w = height, width
         self.render_part, self.assemble = render_part, assemble
+        # a world of one renders straight into the image unless the caller wants the gather
+        # path exercised (tests)
+        self.direct = self.world == 1 and not (always_gather and dist is not None)
         rows = padded_part_rows(height, self.world)
         self.mine = [torch.zeros((rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
         self.image = torch.empty((height, width, channels), dtype=dtype, device=device) if self.rank == 0 else None
-        if self.rank == 0 and self.world > 1:
-            self.chunks = [[torch.empty_like(self.mine[0]) for _ in range(self.world)] for _ in range(2)]
-            self.gathered = torch.empty((self.world, rows, width, channels), dtype=dtype, device=device)
+        if self.rank == 0 and not self.direct:
+            # the gather delivers straight into the slices of one contiguous buffer per frame in flight
+            self.gathered = [torch.empty((self.world, rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
+            self.chunks = [[g[i] for i in range(self.world)] for g in self.gathered]
         else:
             self.chunks, self.gathered = None, None
         self.prev = None
@@ -101,13 +106,12 @@ class BandPipeline:
     def _finish(self, k, work):
         work.wait()
         if self.rank == 0:
-            self.torch.stack(self.chunks[k % 2], 0, out=self.gathered)
-            self.assemble(self.gathered, self.image)
+            self.assemble(self.gathered[k % 2], self.image)
 
     def step(self):
         k = self.k
         self.k += 1
-        if self.world == 1:
+        if self.direct:
             self.render_part(0, 1, self.image)
             return
         buf = self.mine[k % 2]
