@@ -37,6 +37,22 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3     # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2 (
 PEAK_FP32_FMA_TFLOPS = 78.6         # same without packed math
 
 
+def hbm_traffic_bytes(args):
+    """HBM bytes per launch of the render kernel as measured with rocprofv3 PMC passes
+    (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE; tools/prof_hbm.sh); the summary
+    of the latest round under profiles/ is read back, None when there is none for this config."""
+    if args.fast_math or args.stack_size != STACK_SIZE:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_4k_d8s3_strict.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +172,7 @@ def main():
         result["roofline"] = {
             "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "frac_of_unpacked_fma_peak": achieved / PEAK_FP32_FMA_TFLOPS,
-            "traffic": None,
+            "traffic": hbm_traffic_bytes(args),
             "kernel": "rt_kernel<%d,false> (%s)" % (tim.pending_cap, "fast" if args.fast_math else "strict"),
             "kernel_ms_avg": kernel_ms, "kernel_ms_single_launch": tim.kernel_ms,
             "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H),

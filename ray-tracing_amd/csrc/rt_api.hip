@@ -130,6 +130,10 @@ KParams make_kparams(const rt_params *p)
     k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
+    // development aid: RT_WAVE_PROFILE=1 makes rt_count_events return the wave-level block
+    // profile of the instrumented kernel (tools/wave_profile.py) instead of the event counts
+    static const bool wave_profile = getenv("RT_WAVE_PROFILE") != nullptr;
+    k.wave_profile = wave_profile ? 1 : 0;
     for (int i = 0; i < 16; ++i)
         k.sample_off[i] = i < p->spp_grid ? (float)(((double)i + 0.5) / (double)p->spp_grid - 0.5) : 0.0f;
     k.scene = g.layout;

@@ -156,15 +156,37 @@ DEV float dot3(float ax, float ay, float az, float bx, float by, float bz)
 }
 
 // ------------------------------------------------------------------ event counters
+// Two uses of the same LDS counter array in the instrumented flavour: event counts (one per
+// lane and event, the FLOP accounting), or -- wave_mode -- a profile of the code blocks a wave
+// executes (WCNT: once per wave that enters the block with any lane; LCNT: lanes in it).
 template <bool DEBUG> struct Counters {
     unsigned int *lds_ev;
     DEV void add(int) const {}
+    DEV void wave(int) const {}
+    DEV void lanes(int) const {}
 };
 template <> struct Counters<true> {
     unsigned int *lds_ev;
-    DEV void add(int ev) const { atomicAdd(&lds_ev[ev], 1u); }
+    int wave_mode;
+    DEV void add(int ev) const { if (!wave_mode) atomicAdd(&lds_ev[ev], 1u); }
+    DEV void wave(int slot) const
+    {
+        if (wave_mode) {
+            unsigned long long m = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&lds_ev[slot], 1u);
+        }
+    }
+    DEV void lanes(int slot) const { if (wave_mode) atomicAdd(&lds_ev[slot], 1u); }
 };
 #define CNT(ev) cnt.add(ev)
+#define WCNT(slot) cnt.wave(slot)
+#define LCNT(slot) cnt.lanes(slot)
+enum { WP_ITER, WP_ITER_LANES, WP_PAIR, WP_CAND, WP_CAND_LANES, WP_TBOUND, WP_SPHERE, WP_SPHERE_LANES,
+       WP_SPHERE_ROOT2, WP_TORUS, WP_TORUS_LANES, WP_PLANE_DIV, WP_PATH, WP_PATH_LANES, WP_SKY, WP_HIT,
+       WP_HIT_LANES, WP_NORMAL_SPHERE, WP_NORMAL_TORUS, WP_FRESNEL_POW, WP_FRESNEL_DIV, WP_LOCAL, WP_SHADOW,
+       WP_SHADOW_LANES, WP_SPAWN, WP_SPAWN_LANES, WP_PHONG, WP_PHONG_LANES, WP_CHILDREN, WP_REFR, WP_REFR_PUSH,
+       WP_REFL, WP_POP, WP_POP_LOAD, WP_FINISH, WP_START, WP_COUNT };
+static_assert(WP_COUNT <= EV_COUNT, "the wave profile shares the event counter array");
 
 // ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
 #define Q_EPS 1e-7f
@@ -348,9 +370,11 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
                         float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
 {
     CNT(EV_BOUND_TBOUND);
+    WCNT(WP_CAND); LCNT(WP_CAND_LANES);
     // t_bound > closest.t can only hold once something has been hit: while closest.t is
     // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
     if (bt < 1e30f) {
+        WCNT(WP_TBOUND);
         float t_bound = -b - rt_sqrt(disc);
         if (t_bound > bt) return;
     }
@@ -359,6 +383,7 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
     if (kd < 0) {
         // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
         CNT(EV_SPHERE_CALL);
+        WCNT(WP_SPHERE); LCNT(WP_SPHERE_LANES);
         float b2 = 2.0f * b;
         float ds = b2 * b2 - (4.0f * a) * c;
         hit = false; t = 0.0f;
@@ -367,11 +392,12 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
             float two_a = 2.0f * a;
             CNT(EV_SPHERE_ROOT);
             t = rt_div(-b2 - sq, two_a);
-            if (t < 0.0f) { CNT(EV_SPHERE_ROOT); t = rt_div(-b2 + sq, two_a); }
+            if (t < 0.0f) { CNT(EV_SPHERE_ROOT); WCNT(WP_SPHERE_ROOT2); t = rt_div(-b2 + sq, two_a); }
             hit = t > 0.001f;
             if (hit) CNT(EV_SPHERE_HIT);
         }
     } else {
+        WCNT(WP_TORUS); LCNT(WP_TORUS_LANES);
         TorusFrame f = load_torus(lds, L.off_torus, kd);
         hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
         if (hit) CNT(EV_TORUS_HIT);
@@ -387,6 +413,7 @@ DEV void offer_plane(float oy, float dy, int n, float &bt, int &bid, const Count
     bool ok = __builtin_fabsf(dy) > 0.0001f;
     if (ok) {
         CNT(EV_PLANE_T);
+        WCNT(WP_PLANE_DIV);
         float t = rt_div(-1.0f - oy, dy);
         if (t > 0.001f) {
             CNT(EV_PLANE_HIT);
@@ -417,6 +444,7 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     float4 A = make_float4(0, 0, 0, 0), B = A;
     if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
     for (int j = 0; j < npairs; ++j) {
+        WCNT(WP_PAIR);
         v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
         v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
         v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
@@ -633,6 +661,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     const float *sc = HIER ? scene : lds;       // bound records, materials, torus frames, kinds
     Counters<DEBUG> cnt;
     cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + lds_dwords);
+    if constexpr (DEBUG) cnt.wave_mode = kp.wave_profile;
     if (DEBUG) { if (threadIdx.x < EV_COUNT) cnt.lds_ev[threadIdx.x] = 0u; }
     __syncthreads();
 
@@ -700,10 +729,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         thx = thy = thz = 1.0f; cur_ior = 1.0f; depth = 0;
         fr = fg = fb = 0.0f; np = 0; state = ST_PATH; seg = 0;
         CNT(EV_PIXEL_PATH);
+        WCNT(WP_START);
     };
     if (active) start_sample();
 
     while (active) {
+        WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
         if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
         else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
@@ -712,6 +743,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         bool pop = false;       // this lane needs its next ray from the pending slots
 
         if (state == ST_PATH) {
+            WCNT(WP_PATH); LCNT(WP_PATH_LANES);
             if (DEBUG) {
                 if (sample == 0 && seg == kp.capture_seg) { cap_id = (float)id; cap_t = id >= 0 ? t : 0.0f; cap_depth = (float)depth; }
                 seg++;
@@ -719,6 +751,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             if (id < 0) {
                 // sky (:570-580); mix(h, z, t) = h + t*(z - h); the blue channel is exactly 1
                 CNT(EV_SEG_MISS);
+                WCNT(WP_SKY);
                 float tt = 0.5f + 0.5f * dy;
                 float sx = 0.8f + tt * (0.5f - 0.8f);
                 float sy = 0.9f + tt * (0.7f - 0.9f);
@@ -728,6 +761,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 pop = true;
             } else {
                 CNT(EV_SEG_HIT);
+                WCNT(WP_HIT); LCNT(WP_HIT_LANES);
                 // ---- HitInfo of the winner (:93-100, :122-141, :357-372)
                 hx = ox + t * dx; hy = oy + t * dy; hz = oz + t * dz;
                 float h_ior, h_r0, h_eta_in;
@@ -747,10 +781,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     object_centre(sc, id, qx, qy, qz);
                     int kd = reinterpret_cast<const int *>(sc + L.off_kind)[id];
                     if (kd < 0) {
+                        WCNT(WP_NORMAL_SPHERE);
                         float vx = hx - qx, vy = hy - qy, vz = hz - qz;
                         float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
                         nx = vx * rs; ny = vy * rs; nz = vz * rs;
                     } else {
+                        WCNT(WP_NORMAL_TORUS);
                         TorusFrame f = load_torus(sc, L.off_torus, kd);
                         float ocx = ox - qx, ocy = oy - qy, ocz = oz - qz;
                         float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
@@ -789,17 +825,18 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 float r0 = h_r0;
                 eta = entering ? h_eta_in : h_ior;
                 if (entering && cur_ior != 1.0f) {
+                    WCNT(WP_FRESNEL_DIV);
                     r0 = rt_div(n1 - n2, n1 + n2); r0 = r0 * r0;
                     eta = rt_div(n1, n2);
                 }
                 float sin_t2 = (eta * eta) * (1.0f - cos_t * cos_t);
                 if (sin_t2 > 1.0f) { CNT(EV_FRESNEL_TIR); F = 1.0f; }
-                else { CNT(EV_FRESNEL_FULL); F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_t, 5.0f); }
+                else { CNT(EV_FRESNEL_FULL); WCNT(WP_FRESNEL_POW); F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_t, 5.0f); }
                 local = (1.0f - m_refl) - m_transp;
                 pdx = dx; pdy = dy; pdz = dz;
                 if (local > 0.0f) {
                     // phong_lighting -> calculate_light_attenuation set-up (:443-450)
-                    CNT(EV_LOCAL); CNT(EV_ATTEN_FIXED);
+                    CNT(EV_LOCAL); CNT(EV_ATTEN_FIXED); WCNT(WP_LOCAL);
                     float lx = kp.light[0] - hx, ly = kp.light[1] - hy, lz = kp.light[2] - hz;
                     float d2 = dot3(lx, ly, lz, lx, ly, lz);
                     light_dist = rt_sqrt(d2);
@@ -816,6 +853,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             }
         } else {
             // ---- one shadow hop came back (:453-480)
+            WCNT(WP_SHADOW); LCNT(WP_SHADOW_LANES);
             bool lit_done = true;       // attenuation finished -> shade now
             if (id >= 0) {
                 CNT(EV_HOP_HIT_TEST);
@@ -849,12 +887,14 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
 
         if (spawn) {
+            WCNT(WP_SPAWN); LCNT(WP_SPAWN_LANES);
             if (local > 0.0f) {
                 // phong_lighting (:488-514) with attenuation = fil*, light direction = d (still L)
                 float ambr = 0.05f * mr, ambg = 0.05f * mg, ambb = 0.05f * mb;
                 float lcr = ambr, lcg = ambg, lcb = ambb;
                 if ((filb * filb + filg * filg) != -(filr * filr)) {
                     CNT(EV_PHONG_FULL);
+                    WCNT(WP_PHONG); LCNT(WP_PHONG_LANES);
                     float Lx = dx, Ly = dy, Lz = dz;
                     float nlz = nz * Lz, nly = ny * Ly, nlx = nx * Lx;
                     float diff = max0((nlz + nly) + nlx);
@@ -878,9 +918,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             // ---- children (:606-643)
             pop = true;
             if (depth < kp.max_depth - 1) {
+                WCNT(WP_CHILDREN);
                 float onx = osign * nx, ony = osign * ny, onz = osign * nz;
                 if (m_transp > 0.0f) {
                     CNT(EV_REFR_TRY);
+                    WCNT(WP_REFR);
                     float k2 = 1.0f - eta * (eta * (1.0f - dni * dni));
                     float rx = 0.0f, ry = 0.0f, rz = 0.0f;
                     if (!(k2 < 0.0f)) {
@@ -890,6 +932,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     bool valid = -(rz * rz + ry * ry) < rx * rx;
                     if (valid && np < kp.stack_size) {
                         CNT(EV_REFR_PUSH);
+                        WCNT(WP_REFR_PUSH);
                         float omf = 1.0f - F;
                         float qx = hx + rx * 0.001f, qy = hy + ry * 0.001f, qz = hz + rz * 0.001f;
                         float ux = ((thx * omf) * m_transp) * mr;
@@ -920,6 +963,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     if (np < kp.stack_size) {
                         // the reflection ray is the next one visited: continue with it directly
                         CNT(EV_REFL_PUSH);
+                        WCNT(WP_REFL);
                         float two_dni = dni * 2.0f;
                         ox = hx + onx * 0.001f; oy = hy + ony * 0.001f; oz = hz + onz * 0.001f;
                         dx = pdx - two_dni * onx; dy = pdy - two_dni * ony; dz = pdz - two_dni * onz;
@@ -932,7 +976,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
 
         if (pop) {
+            WCNT(WP_POP);
             if (np > 0) {
+                WCNT(WP_POP_LOAD);
                 np--;
                 const int slot = np;
                 if (LDSP) {
@@ -952,6 +998,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 }
             } else {
                 // path finished: next stratified sample of this pixel, or done
+                WCNT(WP_FINISH);
                 if (DEBUG && sample == 0) cap_nseg = seg;
                 if (MULTI) {
                     accr = accr + fr; accg = accg + fg; accb = accb + fb;

@@ -76,6 +76,7 @@ struct KParams {
     int out_f32;            // 0: RGBA8, 1: float4
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
+    int wave_profile;       // debug flavour only: count executed code blocks per wave instead of events
     float sample_off[16];   // (i + 0.5)/spp - 0.5 for i < spp, rounded to binary32
     SceneLayout scene;
     int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
