@@ -138,6 +138,14 @@ const char *rt_event_name(int event);
  * object, n ground plane, -2 no such segment), t, depth, number of segments of the path.  */
 int rt_capture_segment(const rt_params *p, int seg, float *out, size_t out_bytes);
 
+/* Self-test of the strict flavour's arithmetic (no counterpart in the reference, whose sqrt
+ * and division are the CPU's): the kernels run range-restricted forms of the correctly rounded
+ * sqrt, 1/sqrt and division; this compares them on the GPU with the general forms over every
+ * binary32 operand of their ranges (about 4.8e9 evaluations, well under a second).
+ * counts[i] = operands whose results differ: sqrt, 1/sqrt, reciprocal, log2's quotient.
+ * All four must be 0.                                                                     */
+int rt_selftest_math(uint64_t counts[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,7 +63,7 @@ _inited_device = None
 
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
-           "rt_event_flops", "rt_event_name", "rt_capture_segment"]
+           "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math"]
 
 
 def load_library():
@@ -90,6 +90,7 @@ def load_library():
     L.rt_event_name.argtypes = [ci]
     L.rt_event_name.restype = ctypes.c_char_p
     L.rt_capture_segment.argtypes = [vp, ci, vp, sz]
+    L.rt_selftest_math.argtypes = [vp]
     _lib = L
     return L
 
@@ -246,6 +247,15 @@ def capture_segment(scene, camera, w, h, seg, *, max_depth=4, stack_size=3, shad
     out = np.empty((int(h), int(w), 4), dtype=np.float32)
     _check(L.rt_capture_segment(ctypes.addressof(p), int(seg), out.ctypes.data, out.nbytes))
     return out
+
+
+def selftest_math():
+    """Mismatch counts (sqrt, 1/sqrt, reciprocal, log2 quotient) of the strict flavour's
+    range-restricted arithmetic against the general forms, over all operands; all 0."""
+    L = _ensure_init()
+    counts = np.zeros(4, dtype=np.uint64)
+    _check(L.rt_selftest_math(counts.ctypes.data))
+    return counts
 
 
 def frame_flops(events) -> int:

@@ -51,10 +51,64 @@ DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
 #else
-// strict flavour: correctly rounded, as the reference's CPU GL computes them
+// strict flavour: correctly rounded, as the reference's CPU GL computes them.
+//
+// The compiler's expansions of sqrt and of division spend a third of their instructions on
+// operand scaling and on the special values (0, inf, NaN, results near the denormal range).
+// For operands well inside the normal range those steps are identities, so the functions
+// below run the same refinement sequences without them -- the same instructions in the same
+// order, hence the same bits -- and leave every other operand to the compiler's expansion.
+// rt_selftest_kernel compares both forms over every binary32 operand of the guarded ranges.
 DEV float rt_div(float a, float b) { return a / b; }
-DEV float rt_sqrt(float a) { return __builtin_sqrtf(a); }
-DEV float rt_rsq(float a) { return 1.0f / __builtin_sqrtf(a); }
+
+// sqrt for x in [2^-96, 2^96): rsq seed, one coupled Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)),
+// one residual correction
+DEV float sqrt_core(float x)
+{
+    float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r;
+    float h = 0.5f * r;
+    float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    float d = __builtin_fmaf(-g, g, x);
+    h = __builtin_fmaf(h, e, h);
+    return __builtin_fmaf(d, h, g);
+}
+// 1/s for s in [2^-48, 2^48]: rcp seed, Newton step, two residual corrections of the quotient
+DEV float rcp_core(float s)
+{
+    float y = __builtin_amdgcn_rcpf(s);
+    float e = __builtin_fmaf(-s, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float r0 = __builtin_fmaf(-s, y, 1.0f);
+    float q = __builtin_fmaf(r0, y, y);
+    float r1 = __builtin_fmaf(-s, q, 1.0f);
+    return __builtin_fmaf(r1, y, q);
+}
+// a / b for b in [2^-48, 2^48] and a == 0 or |a| in [2^-48, 2^48]
+DEV float div_core(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = a * y;
+    float r0 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r0, y, q);
+    float r1 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r1, y, q);
+}
+// binary32 patterns 0x0f800000 .. 0x6f7fffff are the positive numbers in [2^-96, 2^96)
+DEV bool sqrt_in_core_range(float x) { return (f_bits(x) - 0x0f800000u) < 0x60000000u; }
+DEV float rt_sqrt(float a)
+{
+    if (sqrt_in_core_range(a)) return sqrt_core(a);
+    return __builtin_sqrtf(a);
+}
+DEV float rt_rsq(float a)
+{
+    if (sqrt_in_core_range(a)) return rcp_core(sqrt_core(a));
+    return 1.0f / __builtin_sqrtf(a);
+}
 #endif
 
 // pow(x, y) = exp2(y * log2 x) with the polynomial kernels the reference's CPU GL runs
@@ -67,7 +121,11 @@ DEV float lp_log2(float x)
     uint32_t i = f_bits(x);
     float e = (float)((int)((i & 0x7f800000u) >> 23) - 127);
     float m = bits_f((i & 0x007fffffu) | 0x3f800000u);
+#ifdef RT_FAST
     float y = rt_div(m - 1.0f, m + 1.0f);
+#else
+    float y = div_core(m - 1.0f, m + 1.0f);      // numerator 0 or in [2^-23, 1), denominator in [2, 3)
+#endif
     float z = y * y;
     float z2 = z * z;
     float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f), 0x1.715476p+1f);
@@ -1119,5 +1177,48 @@ int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return launch_variant<16, true, false, true, false>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
 }
+
+#ifndef RT_FAST
+// Exhaustive comparison of the range-restricted sqrt / reciprocal / division cores with the
+// compiler's full expansions.  counts[0]: sqrt over all x in [2^-96, 2^96); counts[1]:
+// 1/sqrt over the same x; counts[2]: 1/s over all s in [2^-48, 2^48]; counts[3]: log2's
+// (m - 1)/(m + 1) over all m in [1, 2).  A count is the number of operands whose results
+// differ in any bit.
+__global__ __launch_bounds__(256) void rt_selftest_kernel(unsigned long long *counts)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t stride = gridDim.x * 256u;
+    unsigned int bad0 = 0, bad1 = 0, bad2 = 0, bad3 = 0;
+    for (uint32_t u = 0x0f800000u + tid; u < 0x6f800000u; u += stride) {
+        float x = bits_f(u);
+        bad0 += f_bits(sqrt_core(x)) != f_bits(__builtin_sqrtf(x));
+        bad1 += f_bits(rcp_core(sqrt_core(x))) != f_bits(1.0f / __builtin_sqrtf(x));
+        if (u - stride < 0x0f800000u) {      // first trip of this thread: the guards themselves
+            bad0 += !sqrt_in_core_range(x);
+            bad0 += sqrt_in_core_range(bits_f(0x0f7fffffu)) + sqrt_in_core_range(bits_f(0x6f800000u)) +
+                    sqrt_in_core_range(0.0f) + sqrt_in_core_range(-1.0f) + sqrt_in_core_range(bits_f(0x7f800000u)) +
+                    sqrt_in_core_range(bits_f(0x7fc00000u)) + sqrt_in_core_range(bits_f(0x00000001u));
+        }
+    }
+    for (uint32_t u = 0x27800000u + tid; u <= 0x57800000u; u += stride) {     // 2^-48 .. 2^48
+        float sv = bits_f(u);
+        bad2 += f_bits(rcp_core(sv)) != f_bits(1.0f / sv);
+    }
+    for (uint32_t u = 0x3f800000u + tid; u < 0x40000000u; u += stride) {
+        float m = bits_f(u);
+        bad3 += f_bits(div_core(m - 1.0f, m + 1.0f)) != f_bits((m - 1.0f) / (m + 1.0f));
+    }
+    if (bad0) atomicAdd(&counts[0], (unsigned long long)bad0);
+    if (bad1) atomicAdd(&counts[1], (unsigned long long)bad1);
+    if (bad2) atomicAdd(&counts[2], (unsigned long long)bad2);
+    if (bad3) atomicAdd(&counts[3], (unsigned long long)bad3);
+}
+
+int launch_selftest(unsigned long long *d_counts, void *stream)
+{
+    hipLaunchKernelGGL(rt_selftest_kernel, dim3(256 * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_counts);
+    return (int)hipGetLastError();
+}
+#endif
 
 }  // namespace RT_NS

@@ -106,5 +106,6 @@ struct LaunchInfo { int vgprs; int lds_bytes; int pending_cap; };
                      float *d_capture, void *stream);                                            \
     }
 
+namespace rt_strict { int launch_selftest(unsigned long long *d_counts, void *stream); }
 RT_DECLARE_FLAVOUR(rt_strict)
 RT_DECLARE_FLAVOUR(rt_fast)

@@ -283,3 +283,11 @@ def test_hierarchy_candidate_queue_overflow(gpu_rt, orc):
     assert f32_identical(fast, plain)
     ref = orc.render(scene, cam.matrix(), cam.focal_length, 200, 120, want_f32=True, **o)["f32"]
     assert f32_identical(fast, ref)
+
+
+def test_range_restricted_arithmetic_equals_general_forms_exhaustively(gpu_rt):
+    """The strict kernels run sqrt / 1/sqrt / log2's quotient without the operand scaling and
+    special-value steps when the operand is well inside the normal range; every binary32
+    operand of those ranges gives the bits of the general (correctly rounded) forms."""
+    counts = gpu_rt.selftest_math()
+    assert counts.tolist() == [0, 0, 0, 0]
