@@ -152,6 +152,11 @@ int hierarchy_min_objects()
     return v;
 }
 
+// the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
+static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && RT_FAN == 8,
+              "node masks of trace_hierarchy are sized for this");
+static_assert(RT_MAX_OBJECTS <= 65536, "slot ids and the candidate queue hold 16-bit object indices");
+
 // Effective bounding radius of an object: the square root of the binary32 value br*br the
 // reference's bounding test uses (fragment_shader.glsl:391-402).
 double bound_radius(const rt_object &o)

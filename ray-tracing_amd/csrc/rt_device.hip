@@ -593,45 +593,60 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
     const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
 
-    // ---- step 1: collect the objects whose bounding test passes
+    // ---- step 1: collect the objects whose bounding test passes.
+    // The top nodes are tested by all lanes together; below them every lane walks its own
+    // list of kept nodes (bit masks), so a wave of incoherent rays pays for the longest list
+    // of any lane, not for the union of all lists.
     int count = 0;
+    unsigned int top_mask = 0;
     for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
-        bool kt[2];
-        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, kt[0], kt[1]);
+        bool k0, k1;
+        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
+        top_mask |= (k0 ? 1u : 0u) << (2 * j);
+        top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
+    }
+    unsigned long long leaf_lo = 0, leaf_hi = 0;        // kept leaf nodes 0..63 / 64..127
+    const int last_leaf_pair = (n1 - 1) >> 1;
+    while (top_mask) {
+        const int tn = __builtin_ctz(top_mask);
+        top_mask &= top_mask - 1;
+        const int first = tn * RT_FAN;                       // first leaf node of this top node
+        const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
+        unsigned int bits = 0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tn = 2 * j + h;
-            if (!(kt[h] && tn < n2)) continue;
-            const int first = tn * RT_FAN;                       // first leaf node of this top node
-            const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
-            for (int kk = 0; kk < ((nleaf + 1) >> 1); ++kk) {
-                bool kl[2];
-                const int lp = (first >> 1) + kk;
-                node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, kl[0], kl[1]);
+        for (int kk = 0; kk < RT_FAN / 2; ++kk) {
+            int lp = (first >> 1) + kk;
+            lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
+            bool k0, k1;
+            node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
+            bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
+            bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
+        }
+        const unsigned long long placed = (unsigned long long)bits << (first & 63);
+        if (first < 64) leaf_lo |= placed; else leaf_hi |= placed;
+    }
+    while (leaf_lo | leaf_hi) {
+        int leaf;
+        if (leaf_lo) { leaf = __builtin_ctzll(leaf_lo); leaf_lo &= leaf_lo - 1; }
+        else { leaf = 64 + __builtin_ctzll(leaf_hi); leaf_hi &= leaf_hi - 1; }
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const int leaf = first + 2 * kk + h2;
-                    if (!(kl[h2] && leaf < n1)) continue;
-                    for (int m = 0; m < RT_LEAF / 2; ++m) {
-                        const int mp = leaf * (RT_LEAF / 2) + m;
-                        const float4 A = memb[2 * mp], B = memb[2 * mp + 1];
-                        // the reference's bounding test (:399-402), operation for operation
-                        v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
-                        v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-                        v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-                        v2f c = oc2 - br2;
-                        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
-                        v2f disc = b * b - c;
-                        if (!(disc.x < 0.0f)) {
-                            if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp];
-                            count++;
-                        }
-                        if (!(disc.y < 0.0f)) {
-                            if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp + 1];
-                            count++;
-                        }
-                    }
-                }
+        for (int m = 0; m < RT_LEAF / 2; ++m) {
+            const int mp = leaf * (RT_LEAF / 2) + m;
+            const float4 A = memb[2 * mp], B = memb[2 * mp + 1];
+            // the reference's bounding test (:399-402), operation for operation
+            v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
+            v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
+            v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+            v2f c = oc2 - br2;
+            v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
+            v2f disc = b * b - c;
+            if (!(disc.x < 0.0f)) {
+                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp];
+                count++;
+            }
+            if (!(disc.y < 0.0f)) {
+                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp + 1];
+                count++;
             }
         }
     }

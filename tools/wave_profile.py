@@ -29,10 +29,14 @@ def main():
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--stack-size", type=int, default=3)
     ap.add_argument("--shadow-hops", type=int, default=2)
+    ap.add_argument("--scene", default="default", choices=["default", "tori", "spheres", "mixed"])
     args = ap.parse_args()
     import torch  # noqa: F401  (before librt355: one HIP runtime per process)
     import rt355
-    ev = rt355.count_events(rt355.default_scene(), rt355.default_camera(), args.w, args.h, max_depth=args.max_depth,
+    scene, cam = {"default": (rt355.default_scene, rt355.default_camera), "tori": (rt355.tori_stress_scene, rt355.tori_stress_camera),
+                  "spheres": (rt355.spheres_deep_scene, rt355.spheres_deep_camera),
+                  "mixed": (rt355.mixed_scene, rt355.mixed_camera)}[args.scene]
+    ev = rt355.count_events(scene(), cam(), args.w, args.h, max_depth=args.max_depth,
                             stack_size=args.stack_size, shadow_hops=args.shadow_hops)
     waves = ((args.w + 15) // 16) * ((args.h + 15) // 16) * 4
     print(f"waves {waves}")
