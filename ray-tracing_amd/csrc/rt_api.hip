@@ -34,6 +34,9 @@ struct State {
     void *d_out = nullptr;          // staging for rt_render / debug launches
     size_t d_out_cap = 0;
     unsigned long long *d_events = nullptr;
+    unsigned int *d_work = nullptr;     // tile queue head of the persistent-wave kernels
+    int resident_workgroups = 2048;
+    unsigned int work_seq = 0;
     rt_timing timing{};
     char err[512] = "";
 } g;
@@ -127,6 +130,13 @@ KParams make_kparams(const rt_params *p)
     k.max_depth = p->max_depth; k.stack_size = p->stack_size; k.hops = p->shadow_hops; k.spp = p->spp_grid;
     k.bottom_up = (p->flags & RT_FLAG_BOTTOM_UP) ? 1 : 0;
     k.part = p->part; k.nparts = p->nparts;
+    {
+        int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+        k.my_bands = (bands - p->part + p->nparts - 1) / p->nparts;
+    }
+    // consecutive launches use different counters: launches on different streams may overlap
+    k.work_counter = g.d_work + (g.work_seq++ % 64u);
+    k.resident_workgroups = g.resident_workgroups;
     k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
@@ -308,6 +318,13 @@ int rt_init(int device)
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), 256));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        // the persistent-wave kernels run at 2-3 waves per SIMD = 2-3 workgroups per CU
+        g.resident_workgroups = prop.multiProcessorCount * 3;
+    }
     g.device = device;
     g.inited = true;
     g.err[0] = 0;
@@ -322,6 +339,7 @@ void rt_shutdown(void)
     if (g.d_scene) hipFree(g.d_scene);
     if (g.d_out) hipFree(g.d_out);
     if (g.d_events) hipFree(g.d_events);
+    if (g.d_work) hipFree(g.d_work);
     hipEventDestroy(g.ev0);
     hipEventDestroy(g.ev1);
     hipStreamDestroy(g.stream);

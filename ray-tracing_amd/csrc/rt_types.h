@@ -73,6 +73,9 @@ struct KParams {
     int max_depth, stack_size, hops, spp;
     int bottom_up;          // output row order
     int part, nparts;       // band split
+    int my_bands;           // 16-row bands this part renders
+    unsigned int *work_counter;   // tile queue head of the persistent-wave kernels (zeroed per launch)
+    int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
     int out_f32;            // 0: RGBA8, 1: float4
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
