@@ -138,6 +138,15 @@ const char *rt_event_name(int event);
  * object, n ground plane, -2 no such segment), t, depth, number of segments of the path.  */
 int rt_capture_segment(const rt_params *p, int seg, float *out, size_t out_bytes);
 
+/* Host-only diagnostic (no GPU, no rt_init needed): validates a scene exactly as rt_set_scene
+ * does and returns what it would stage on the GPU.  layout = { n, ntori, off_material,
+ * off_torus, off_kind, total_dwords, leaf nodes, top nodes, off_top, off_leaf, off_member,
+ * off_slot_id, slots per leaf, leaves per top node, 0, 0 } (offsets in dwords; node counts 0
+ * when the scene is too small for the sphere hierarchy); blob (may be NULL) receives
+ * total_dwords dwords followed by the 4 floats of the sphere that encloses the scene.
+ * No counterpart in the reference (its scene travels as GL uniforms, main.py:283-296).   */
+int rt_stage_scene_host(const rt_object *objs, int n, float *blob, size_t blob_dwords, int32_t layout[16]);
+
 /* Self-test of the strict flavour's arithmetic (no counterpart in the reference, whose sqrt
  * and division are the CPU's): the kernels run range-restricted forms of the correctly rounded
  * sqrt, 1/sqrt and division; this compares them on the GPU with the general forms over every

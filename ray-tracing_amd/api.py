@@ -63,7 +63,7 @@ _inited_device = None
 
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
-           "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math"]
+           "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host"]
 
 
 def load_library():
@@ -91,6 +91,7 @@ def load_library():
     L.rt_event_name.restype = ctypes.c_char_p
     L.rt_capture_segment.argtypes = [vp, ci, vp, sz]
     L.rt_selftest_math.argtypes = [vp]
+    L.rt_stage_scene_host.argtypes = [vp, ci, vp, sz, vp]
     _lib = L
     return L
 
@@ -247,6 +248,22 @@ def capture_segment(scene, camera, w, h, seg, *, max_depth=4, stack_size=3, shad
     out = np.empty((int(h), int(w), 4), dtype=np.float32)
     _check(L.rt_capture_segment(ctypes.addressof(p), int(seg), out.ctypes.data, out.nbytes))
     return out
+
+
+def stage_scene_host(scene):
+    """What rt_set_scene would stage for `scene`, computed on the host only (no GPU needed):
+    returns (layout dict, blob float32 array, scene sphere (cx, cy, cz, R))."""
+    L = load_library()
+    objs = pack_scene(scene)
+    layout = np.zeros(16, dtype=np.int32)
+    _check(L.rt_stage_scene_host(ctypes.addressof(objs) if len(scene) else None, len(scene), None, 0, layout.ctypes.data))
+    total = int(layout[5])
+    blob = np.zeros(total + 4, dtype=np.float32)
+    _check(L.rt_stage_scene_host(ctypes.addressof(objs) if len(scene) else None, len(scene), blob.ctypes.data, blob.size,
+                                 layout.ctypes.data))
+    keys = ["n", "ntori", "off_material", "off_torus", "off_kind", "total_dwords", "n1", "n2", "off_top", "off_leaf",
+            "off_member", "off_slot_id", "leaf", "fan"]
+    return dict(zip(keys, (int(v) for v in layout))), blob[:total], tuple(float(v) for v in blob[total:])
 
 
 def selftest_math():

@@ -346,9 +346,9 @@ void rt_shutdown(void)
     g = State{};
 }
 
-int rt_set_scene(const rt_object *objs, int n)
+// Validation + staging of a scene on the host: the blob the kernels read and its layout.
+static int pack_scene_host(const rt_object *objs, int n, SceneLayout &L_out, std::vector<float> &blob_out)
 {
-    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
     if (n < 0 || (n > 0 && !objs)) return fail(RT_E_ARG, "bad scene pointer/count");
     if (n > RT_MAX_OBJECTS) return fail(RT_E_SCENE, "%d objects exceed the limit of %d", n, RT_MAX_OBJECTS);
     int ntori = 0;
@@ -400,6 +400,18 @@ int rt_set_scene(const rt_object *objs, int n)
         slot++;
     }
     if (L.n1 > 0) build_hierarchy(objs, n, L, blob.data());
+    L_out = L;
+    blob_out.swap(blob);
+    return RT_OK;
+}
+
+int rt_set_scene(const rt_object *objs, int n)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    SceneLayout L;
+    std::vector<float> blob;
+    int rc = pack_scene_host(objs, n, L, blob);
+    if (rc) return rc;
     size_t bytes = (size_t)L.total_dwords * sizeof(float);
     if (bytes < 16) bytes = 16;
     if (bytes > g.d_scene_cap) {
@@ -414,6 +426,25 @@ int rt_set_scene(const rt_object *objs, int n)
     HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
     g.layout = L;
     g.have_scene = true;
+    return RT_OK;
+}
+
+int rt_stage_scene_host(const rt_object *objs, int n, float *blob, size_t blob_dwords, int32_t layout[16])
+{
+    SceneLayout L;
+    std::vector<float> staged;
+    int rc = pack_scene_host(objs, n, L, staged);
+    if (rc) return rc;
+    if (!layout) return fail(RT_E_ARG, "layout is null");
+    const int32_t v[16] = {L.n, L.ntori, L.off_material, L.off_torus, L.off_kind, L.total_dwords, L.n1, L.n2,
+                           L.off_top, L.off_leaf, L.off_member, L.off_slot_id, RT_LEAF, RT_FAN, 0, 0};
+    std::memcpy(layout, v, sizeof v);
+    float hs[4] = {L.hc[0], L.hc[1], L.hc[2], L.hR};
+    if (blob) {
+        if (blob_dwords < (size_t)L.total_dwords + 4) return fail(RT_E_SIZE, "blob needs %d dwords", L.total_dwords + 4);
+        std::memcpy(blob, staged.data(), (size_t)L.total_dwords * sizeof(float));
+        std::memcpy(blob + L.total_dwords, hs, sizeof hs);
+    }
     return RT_OK;
 }
 

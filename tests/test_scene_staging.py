@@ -1,0 +1,87 @@
+"""Host-side scene staging (what rt_set_scene uploads), checked without a GPU through the
+host-only entry point: per-object invariants against the oracle's, and the invariants the
+sphere hierarchy must satisfy for the accelerated trace to be exact (every object inside its
+leaf node, every leaf inside its top node, everything inside the scene sphere, slot ids a
+permutation, empty slots impossible to hit)."""
+import numpy as np
+import pytest
+
+
+def bound_records(blob, count, off):
+    """Pair-interleaved {cx0 cx1 cy0 cy1}{cz0 cz1 r0 r1} records -> (count, 4) array."""
+    rec = blob[off:off + 8 * ((count + 1) // 2)].reshape(-1, 8)
+    out = np.empty((2 * rec.shape[0], 4), dtype=np.float32)
+    out[0::2] = rec[:, [0, 2, 4, 6]]
+    out[1::2] = rec[:, [1, 3, 5, 7]]
+    return out[:count], out
+
+
+def test_small_scene_has_no_hierarchy_and_the_shader_invariants(rt):
+    scene = rt.default_scene()
+    L, blob, sphere = rt.stage_scene_host(scene)
+    assert (L["n"], L["ntori"], L["n1"], L["n2"]) == (5, 1, 0, 0)
+    rec, padded = bound_records(blob, 5, 0)
+    for i, o in enumerate(scene):
+        assert rec[i, :3].tolist() == [np.float32(c) for c in o["center"]]
+        br = np.float32(o["radius"]) if o["type"] == 1 else np.float32(o["major_radius"]) + np.float32(o["minor_radius"])
+        assert rec[i, 3] == br * br                                   # fragment_shader.glsl:391-402
+    assert padded[5, 3] == -np.inf                                    # odd count: the pad can never pass
+    mat = blob[L["off_material"]:L["off_material"] + 40].reshape(5, 8)
+    ior = np.float32(1.5)
+    q = (np.float32(1.0) - ior) / (np.float32(1.0) + ior)
+    assert mat[0, 6] == q * q and mat[0, 7] == np.float32(1.0) / ior  # Fresnel constants, :525-528
+    kind = blob[L["off_kind"]:L["off_kind"] + 5].view(np.int32)
+    assert kind.tolist() == [-1, -1, -1, -1, 0]
+    tor = blob[L["off_torus"]:L["off_torus"] + 16]
+    # normal (0,1,0): |w.y| > 0.99 selects the x axis as helper (:315-317)
+    assert tor[3:6].tolist() == [0.0, 1.0, 0.0] and tor[9] == np.float32(0.8)
+    assert tor[10] == np.float32(0.8) * np.float32(0.8) and tor[11] == np.float32(0.2) * np.float32(0.2)
+
+
+@pytest.mark.parametrize("which,n", [("mixed", 1024), ("mixed", 1000), ("mixed", 41), ("spheres", 256), ("tori", 64),
+                                     ("large", 0), ("large", 5), ("row", 120)])
+def test_hierarchy_invariants(rt, which, n):
+    if which == "mixed":
+        scene = rt.mixed_scene(n)
+    elif which == "spheres":
+        scene = rt.spheres_deep_scene(n)
+    elif which == "tori":
+        scene = rt.tori_stress_scene(n)
+    elif which == "row":
+        scene = rt.sphere_row_scene(n)
+    else:
+        scene = rt.random_large_scene(n)[0]
+    n = len(scene)
+    L, blob, (sx, sy, sz, sR) = rt.stage_scene_host(scene)
+    leaf, fan = L["leaf"], L["fan"]
+    assert L["n1"] == -(-n // leaf) and L["n2"] == -(-L["n1"] // fan)
+    obj, _ = bound_records(blob, n, 0)
+    top, _ = bound_records(blob, L["n2"], L["off_top"])
+    leafn, _ = bound_records(blob, L["n1"], L["off_leaf"])
+    memb, _ = bound_records(blob, L["n1"] * leaf, L["off_member"])
+    ids = blob[L["off_slot_id"]:L["off_slot_id"] + L["n1"] * leaf // 2].view(np.uint16)
+    # the occupied slots are a permutation of the objects and carry their own bound records
+    assert sorted(ids[:n].tolist()) == list(range(n))
+    assert np.array_equal(memb[:n], obj[ids[:n]])
+    assert (memb[n:, 3] == -np.inf).all()
+    c = obj[:, :3].astype(np.float64)
+    r = np.sqrt(obj[:, 3].astype(np.float64))
+    for s in range(n):
+        i = ids[s]
+        lf, tp = s // leaf, s // (leaf * fan)
+        for node in (leafn[lf], top[tp], np.array([sx, sy, sz, sR], dtype=np.float32)):
+            d = np.linalg.norm(c[i] - node[:3].astype(np.float64))
+            assert d + r[i] <= float(node[3]), (s, i)
+    # nodes themselves lie inside the scene sphere (the ray-level slack is derived from it)
+    for node in list(leafn) + list(top):
+        d = np.linalg.norm(node[:3].astype(np.float64) - np.array([sx, sy, sz]))
+        assert d + float(node[3]) <= sR * (1 + 1e-6)
+
+
+def test_staging_rejects_what_set_scene_rejects(rt):
+    bad = rt.default_scene()
+    bad[2]["center"] = [0.0, float("nan"), 0.0]
+    with pytest.raises(rt.RtError):
+        rt.stage_scene_host(bad)
+    L, blob, _ = rt.stage_scene_host([])
+    assert L["n"] == 0 and L["n1"] == 0
