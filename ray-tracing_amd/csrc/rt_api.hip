@@ -37,6 +37,10 @@ struct State {
     unsigned int *d_work = nullptr;     // tile queue head of the persistent-wave kernels
     int resident_workgroups = 2048;
     unsigned int work_seq = 0;
+    float *d_pend_ws = nullptr;         // pending-ray workspace of the persistent-wave kernels
+    hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
+    bool ws_busy = false;
+    hipStream_t ws_stream = nullptr;
     rt_timing timing{};
     char err[512] = "";
 } g;
@@ -137,6 +141,7 @@ KParams make_kparams(const rt_params *p)
     // consecutive launches use different counters: launches on different streams may overlap
     k.work_counter = g.d_work + (g.work_seq++ % 64u);
     k.resident_workgroups = g.resident_workgroups;
+    k.pend_ws = g.d_pend_ws;
     k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
@@ -317,13 +322,14 @@ int rt_init(int device)
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipEventCreateWithFlags(&g.ws_event, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), 256));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        // the persistent-wave kernels run at 2-3 waves per SIMD = 2-3 workgroups per CU
-        g.resident_workgroups = prop.multiProcessorCount * 3;
+        // the persistent-wave kernels run at up to 4 waves per SIMD = 4 workgroups per CU
+        g.resident_workgroups = prop.multiProcessorCount * 4;
     }
     g.device = device;
     g.inited = true;
@@ -340,8 +346,10 @@ void rt_shutdown(void)
     if (g.d_out) hipFree(g.d_out);
     if (g.d_events) hipFree(g.d_events);
     if (g.d_work) hipFree(g.d_work);
+    if (g.d_pend_ws) hipFree(g.d_pend_ws);
     hipEventDestroy(g.ev0);
     hipEventDestroy(g.ev1);
+    hipEventDestroy(g.ws_event);
     hipStreamDestroy(g.stream);
     g = State{};
 }
@@ -421,6 +429,13 @@ int rt_set_scene(const rt_object *objs, int n)
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_scene), cap));
         g.d_scene_cap = cap;
     }
+    // large scenes run the persistent-wave kernels, whose pending rays live in a workspace
+    // sliced by resident workgroup (184 MB on a 256-CU GPU); allocated once, on first need
+    static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
+    if (L.n1 > 0 && !g.d_pend_ws) {
+        size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
+    }
     // blocking copy: later launches on any stream see the new scene
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
@@ -467,10 +482,19 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     KParams kp = make_kparams(p);
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
     LaunchInfo info{};
+    // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
+    // waits (on the GPU) for the previous one, whatever streams the two are on
+    const bool shares_workspace = kp.use_hierarchy != 0;
+    if (shares_workspace && g.ws_busy && s != g.ws_stream) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)
                                              : rt_strict::launch_render(kp, g.d_scene, d_out, s, &info);
     if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (shares_workspace) {
+        HIP_TRY(hipEventRecord(g.ws_event, s));
+        g.ws_busy = true;
+        g.ws_stream = s;
+    }
     if (timed) { HIP_TRY(hipEventRecord(g.ev1, s)); g.ev_pending = true; }
     g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap;
     return RT_OK;

@@ -718,8 +718,13 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // count), a new tile being taken when it runs out.  Path-tree sizes differ by orders of
 // magnitude between neighbouring pixels at depth 16, so without this most lanes of a wave
 // wait for its longest pixel.
-template <int CAP, bool DEBUG, bool LDSP, bool MULTI, bool HIER, bool REFILL>
-__global__ __launch_bounds__(256, LDSP ? RT_WAVES_PER_EU_LDSP : (HIER && CAP <= 7) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
+// PEND: where the pending-ray slots live: PEND_REG registers (CAP of them, compare/select
+// addressing), PEND_LDS ([slot][field][thread] after the scene), PEND_GLOBAL (same layout in a
+// per-workgroup slice of a global workspace; persistent-wave kernels only, whose grid is
+// bounded by the number of resident workgroups).
+enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2 };
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
+__global__ __launch_bounds__(256, PEND == PEND_LDS ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
@@ -773,14 +778,19 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     float accr = 0, accg = 0, accb = 0;                    // sum over samples
     int sample = 0;
     int np = 0;                                            // pending refraction rays
-    Pending<LDSP ? 1 : CAP> pend;
+    constexpr bool LDSP = PEND == PEND_LDS;
+    constexpr bool MEMP = PEND != PEND_REG;             // slots in memory, not registers
+    Pending<MEMP ? 1 : CAP> pend;
 #pragma unroll
-    for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
+    for (int k = 0; k < (MEMP ? 1 : CAP); ++k) {
         pend.ox[k] = pend.oy[k] = pend.oz[k] = 0; pend.dx[k] = pend.dy[k] = pend.dz[k] = 0;
         pend.tx[k] = pend.ty[k] = pend.tz[k] = 0; pend.ior[k] = 1; pend.depth[k] = 0;
     }
     // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
     float *pend_lds = lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
+    float *pend_mem = PEND == PEND_GLOBAL ? kp.pend_ws + (size_t)blockIdx.x * (RT_PEND_MAX * 11 * 256) + threadIdx.x
+                                           : pend_lds;
+    (void)LDSP;
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
     unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3)) + threadIdx.x;
     int state = ST_PATH;
@@ -1090,15 +1100,15 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         float uy = ((thy * omf) * m_transp) * mg;
                         float uz = ((thz * omf) * m_transp) * mb;
                         const int slot = np;
-                        if (LDSP) {
-                            float *q = pend_lds + slot * (11 * 256);
+                        if (MEMP) {
+                            float *q = pend_mem + slot * (11 * 256);
                             q[0 * 256] = qx; q[1 * 256] = qy; q[2 * 256] = qz;
                             q[3 * 256] = rx; q[4 * 256] = ry; q[5 * 256] = rz;
                             q[6 * 256] = ux; q[7 * 256] = uy; q[8 * 256] = uz;
                             q[9 * 256] = n2; q[10 * 256] = __int_as_float(depth + 1);
                         } else {
 #pragma unroll
-                            for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
+                            for (int k = 0; k < (MEMP ? 1 : CAP); ++k) {
                                 SEL_STORE(pend.ox, qx); SEL_STORE(pend.oy, qy); SEL_STORE(pend.oz, qz);
                                 SEL_STORE(pend.dx, rx); SEL_STORE(pend.dy, ry); SEL_STORE(pend.dz, rz);
                                 SEL_STORE(pend.tx, ux); SEL_STORE(pend.ty, uy); SEL_STORE(pend.tz, uz);
@@ -1132,15 +1142,15 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 WCNT(WP_POP_LOAD);
                 np--;
                 const int slot = np;
-                if (LDSP) {
-                    const float *q = pend_lds + slot * (11 * 256);
+                if (MEMP) {
+                    const float *q = pend_mem + slot * (11 * 256);
                     ox = q[0 * 256]; oy = q[1 * 256]; oz = q[2 * 256];
                     dx = q[3 * 256]; dy = q[4 * 256]; dz = q[5 * 256];
                     thx = q[6 * 256]; thy = q[7 * 256]; thz = q[8 * 256];
                     cur_ior = q[9 * 256]; depth = __float_as_int(q[10 * 256]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < (LDSP ? 1 : CAP); ++k) {
+                    for (int k = 0; k < (MEMP ? 1 : CAP); ++k) {
                         SEL_LOAD(ox, pend.ox); SEL_LOAD(oy, pend.oy); SEL_LOAD(oz, pend.oz);
                         SEL_LOAD(dx, pend.dx); SEL_LOAD(dy, pend.dy); SEL_LOAD(dz, pend.dz);
                         SEL_LOAD(thx, pend.tx); SEL_LOAD(thy, pend.ty); SEL_LOAD(thz, pend.tz);
@@ -1180,13 +1190,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, bool LDSP, bool MULTI, bool HIER, bool REFILL>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
+    constexpr bool LDSP = PEND == PEND_LDS;
     static_assert(!(LDSP && HIER), "the LDS pending slots and the candidate queue share one region");
+    static_assert(PEND != PEND_GLOBAL || REFILL, "the global pending-ray workspace is sliced by persistent workgroup");
+    if (PEND == PEND_GLOBAL && !kp.pend_ws) return (int)hipErrorInvalidValue;
     static_assert(!REFILL || (HIER && !DEBUG), "pixel refill is built for the large-scene kernels only");
-    auto kfn = rt_kernel<CAP, DEBUG, LDSP, MULTI, HIER, REFILL>;
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
@@ -1238,19 +1251,19 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
     const bool multi = kp.spp > 1;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
-    (multi ? launch_variant<CAP_, false, LDSP_, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
-           : launch_variant<CAP_, false, LDSP_, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
-#define RT_LAUNCH_HIER(CAP_, REFILL_)                                                                       \
-    (multi ? launch_variant<CAP_, false, false, true, true, REFILL_>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
-           : launch_variant<CAP_, false, false, false, true, REFILL_>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+    (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
+           : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+#define RT_LAUNCH_HIER(CAP_, PEND_)                                                                         \
+    (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
+           : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info))
     // Large scenes run as persistent waves with pixel refill (measured 1.1-2.4x there: 64 tori
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
     // 2250 -> 928 ms).  The 5-object scene keeps one pixel per lane: there the lanes' loss of
     // lock-step costs more than the idle lanes (depth 8 / stack 8: 0.96 -> 1.53 ms).
     if (kp.use_hierarchy && kp.scene.n1 > 0) {
-        if (need <= 3) return RT_LAUNCH_HIER(3, true);
-        if (need <= 7) return RT_LAUNCH_HIER(7, true);
-        return RT_LAUNCH_HIER(16, true);
+        // pending rays in the global workspace: 123 VGPRs whatever the stack size (register slots:
+        // 147 / 168 / 256 for 3 / 7 / 16), measured 1.06-1.46x faster than register slots
+        return RT_LAUNCH_HIER(RT_PEND_MAX, PEND_GLOBAL);
     }
     if (need <= 3) {
         // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
@@ -1269,7 +1282,7 @@ int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_
                  void *stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return launch_variant<16, true, false, true, false, false>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
+    return launch_variant<16, true, PEND_REG, true, false, false>(kp, d_scene, nullptr, d_events, d_capture, s, nullptr);
 }
 
 #ifndef RT_FAST

@@ -36,6 +36,7 @@ struct SceneLayout {
 
 #define RT_LEAF 8        // object slots per leaf node (even)
 #define RT_FAN 8         // leaf nodes per top node (even)
+#define RT_PEND_MAX 16   // pending-ray slots per lane in the global workspace (= RT_MAX_PENDING)
 #define RT_QUEUE 32      // per-ray candidate queue entries (16 bits each, in LDS)
 
 static inline SceneLayout scene_layout(int n, int ntori, bool hierarchy)
@@ -76,6 +77,7 @@ struct KParams {
     int my_bands;           // 16-row bands this part renders
     unsigned int *work_counter;   // tile queue head of the persistent-wave kernels (zeroed per launch)
     int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
+    float *pend_ws;               // pending-ray workspace: resident_workgroups x RT_PEND_MAX x 11 x 256 floats
     int out_f32;            // 0: RGBA8, 1: float4
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
