@@ -330,6 +330,11 @@ int rt_init(int device)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         // the persistent-wave kernels run at up to 4 waves per SIMD = 4 workgroups per CU
         g.resident_workgroups = prop.multiProcessorCount * 4;
+        // pending-ray workspace of the persistent-wave kernels, sliced by resident workgroup
+        // (184 MB on a 256-CU GPU)
+        static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
+        size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
     }
     g.device = device;
     g.inited = true;
@@ -429,13 +434,6 @@ int rt_set_scene(const rt_object *objs, int n)
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_scene), cap));
         g.d_scene_cap = cap;
     }
-    // large scenes run the persistent-wave kernels, whose pending rays live in a workspace
-    // sliced by resident workgroup (184 MB on a 256-CU GPU); allocated once, on first need
-    static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
-    if (L.n1 > 0 && !g.d_pend_ws) {
-        size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
-    }
     // blocking copy: later launches on any stream see the new scene
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
@@ -484,7 +482,8 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     LaunchInfo info{};
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
     // waits (on the GPU) for the previous one, whatever streams the two are on
-    const bool shares_workspace = kp.use_hierarchy != 0;
+    const int pend_need = p->stack_size < p->max_depth - 1 ? p->stack_size : p->max_depth - 1;
+    const bool shares_workspace = kp.use_hierarchy != 0 || pend_need > 3;
     if (shares_workspace && g.ws_busy && s != g.ws_stream) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)

@@ -856,7 +856,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             if (!active) break;
         } else {
             const unsigned long long need = __ballot(!active);
-            if (need != 0ull && (pool_next < 64 || !exhausted)) {
+            // whole_tiles: pixels are handed out only when the whole wave is idle, i.e. a wave
+            // renders tile after tile with its lanes in lock-step (small scenes)
+            if (need != 0ull && (!kp.whole_tiles || need == ~0ull) && (pool_next < 64 || !exhausted)) {
                 const int nneed = __popcll(need);
                 const int my = __builtin_amdgcn_mbcnt_hi((unsigned int)(need >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)need, 0u));
@@ -893,8 +895,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 if (exhausted && pool_next >= 64) break;
                 continue;
             }
-            if (!active) continue;       // this lane idles until pixels are handed out again
         }
+        // One trace + shading step of the lanes that have a pixel.  Idle lanes skip forward to
+        // the end of the loop body (never `continue`: a back edge taken by idle lanes alone
+        // would let them spin in a loop of their own while the busy lanes wait to reconverge).
+        do {
+        if (REFILL && !active) break;
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
         if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
@@ -1174,6 +1180,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 if (REFILL && !active) write_pixel();
             }
         }
+        } while (false);
     }
 
     // ---- framebuffer write
@@ -1198,7 +1205,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     static_assert(!(LDSP && HIER), "the LDS pending slots and the candidate queue share one region");
     static_assert(PEND != PEND_GLOBAL || REFILL, "the global pending-ray workspace is sliced by persistent workgroup");
     if (PEND == PEND_GLOBAL && !kp.pend_ws) return (int)hipErrorInvalidValue;
-    static_assert(!REFILL || (HIER && !DEBUG), "pixel refill is built for the large-scene kernels only");
+    static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
@@ -1265,6 +1272,20 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         // 147 / 168 / 256 for 3 / 7 / 16), measured 1.06-1.46x faster than register slots
         return RT_LAUNCH_HIER(RT_PEND_MAX, PEND_GLOBAL);
     }
+    if (need > 7) {
+        // Small scene, very deep stack: persistent waves that take whole tiles (lanes stay in
+        // lock-step) with the pending rays in the global workspace, 123 VGPRs instead of 256 +
+        // spills for 16 register-resident slots (default scene 4K depth 16 stack 16: 8.9 -> 3.2
+        // ms).  With 4-7 slots the register variant wins (0.96 vs 1.65 ms at depth 8 stack 8:
+        // a pop from the workspace costs a memory round trip that short iterations cannot hide).
+        static const bool reg_pend = getenv("RT_PEND_REG") != nullptr;     // experiments
+        if (!reg_pend) {
+            KParams kw = kp;
+            kw.whole_tiles = 1;
+            return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
+                         : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
+        }
+    }
     if (need <= 3) {
         // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
         // CU next to a small scene, and frees the registers for a fourth wave per SIMD
@@ -1272,7 +1293,14 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         if (!no_ldsp && lds <= 40 * 1024) return RT_LAUNCH(3, true);
         return RT_LAUNCH(3, false);
     }
-    if (need <= 7) return RT_LAUNCH(7, false);
+    if (need <= 7) {
+        // 7 slots in LDS = 77 KB per workgroup: two workgroups per CU, the same 2 waves per SIMD
+        // the 191-VGPR register variant reaches, without its compare/select addressing
+        // (4K depth 8 stack 8: 0.96 -> 0.91 ms)
+        size_t lds = (size_t)kp.scene.total_dwords * 4 + 7 * 11 * 256 * 4;
+        if (!no_ldsp && lds <= 80 * 1024) return RT_LAUNCH(7, true);
+        return RT_LAUNCH(7, false);
+    }
     return RT_LAUNCH(16, false);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_HIER

@@ -77,6 +77,7 @@ struct KParams {
     int my_bands;           // 16-row bands this part renders
     unsigned int *work_counter;   // tile queue head of the persistent-wave kernels (zeroed per launch)
     int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
+    int whole_tiles;              // persistent waves take whole 8x8 tiles only (no per-lane refill)
     float *pend_ws;               // pending-ray workspace: resident_workgroups x RT_PEND_MAX x 11 x 256 floats
     int out_f32;            // 0: RGBA8, 1: float4
     int polish;             // Newton polish on torus roots
