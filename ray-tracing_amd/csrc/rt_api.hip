@@ -36,7 +36,6 @@ struct State {
     unsigned long long *d_events = nullptr;
     unsigned int *d_work = nullptr;     // tile queue head of the persistent-wave kernels
     int resident_workgroups = 2048;
-    unsigned int work_seq = 0;
     float *d_pend_ws = nullptr;         // pending-ray workspace of the persistent-wave kernels
     hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
     bool ws_busy = false;
@@ -138,8 +137,7 @@ KParams make_kparams(const rt_params *p)
         int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
         k.my_bands = (bands - p->part + p->nparts - 1) / p->nparts;
     }
-    // consecutive launches use different counters: launches on different streams may overlap
-    k.work_counter = g.d_work + (g.work_seq++ % 64u);
+    k.work_counter = g.d_work;      // launches that use the queue are ordered on the GPU (workspace event)
     k.resident_workgroups = g.resident_workgroups;
     k.pend_ws = g.d_pend_ws;
     k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
@@ -324,7 +322,7 @@ int rt_init(int device)
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreateWithFlags(&g.ws_event, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), 256));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int)));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -483,7 +481,7 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
     // waits (on the GPU) for the previous one, whatever streams the two are on
     const int pend_need = p->stack_size < p->max_depth - 1 ? p->stack_size : p->max_depth - 1;
-    const bool shares_workspace = kp.use_hierarchy != 0 || pend_need > 3;
+    const bool shares_workspace = kp.use_hierarchy != 0 || pend_need > 7;      // the persistent-wave kernels
     if (shares_workspace && g.ws_busy && s != g.ws_stream) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)

@@ -848,6 +848,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     const int tiles_x8 = (kp.w + 7) >> 3;
     const int ntiles = tiles_x8 * (kp.my_bands * 2);
     int pool_tile = -1, pool_next = 64;
+    int sq = (int)((blockIdx.x * 4u + (unsigned int)wave) % RT_SUBQUEUES), sq_tried = 0;
     bool exhausted = false;
     if (!REFILL && active) start_sample();
 
@@ -865,11 +866,25 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 const bool cross = pool_next + nneed > 64;
                 int new_tile = -1;
                 if (cross && !exhausted) {
-                    unsigned int tk = 0;
-                    if (lane == 0) tk = atomicAdd(kp.work_counter, 1u);
-                    tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
-                    if (tk < (unsigned int)ntiles) new_tile = (int)tk;
-                    else exhausted = true;
+                    // The queue is RT_SUBQUEUES interleaved sub-queues (sub-queue q holds the tiles
+                    // t = q mod RT_SUBQUEUES, in raster order), each behind its own counter: one
+                    // counter for the whole GPU sustains only ~1e8 operations per second, which
+                    // bounded frames of cheap tiles; interleaving keeps all waves in the same
+                    // region of the frame.  A wave drains the sub-queue it starts on, then moves
+                    // on to the next one that still has tiles.
+                    bool got = false;
+                    while (sq_tried < RT_SUBQUEUES) {
+                        const int cnt = (ntiles - sq + RT_SUBQUEUES - 1) / RT_SUBQUEUES;   // tiles of sub-queue sq
+                        if (cnt > 0) {
+                            unsigned int tk = 0;
+                            if (lane == 0) tk = atomicAdd(kp.work_counter + sq * RT_SUBQUEUE_STRIDE, 1u);
+                            tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+                            if (tk < (unsigned int)cnt) { new_tile = (int)tk * RT_SUBQUEUES + sq; got = true; break; }
+                        }
+                        sq = sq + 1 == RT_SUBQUEUES ? 0 : sq + 1;
+                        sq_tried++;
+                    }
+                    if (!got) exhausted = true;
                 }
                 if (!active) {
                     int idx = pool_next + my;
@@ -1196,6 +1211,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     }
 }
 
+__global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
+
 // ------------------------------------------------------------------ launchers
 template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
@@ -1230,8 +1247,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
         int wgs = (ntiles + 3) / 4;
         if (wgs > kp.resident_workgroups) wgs = kp.resident_workgroups;
         grid = dim3(wgs < 1 ? 1 : wgs, 1);
-        hipError_t em = hipMemsetAsync(kp.work_counter, 0, sizeof(unsigned int), stream);
-        if (em != hipSuccess) return (int)em;
+        hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(RT_SUBQUEUES), 0, stream, kp.work_counter);
     }
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, kp, d_scene, d_out, d_ev, d_cap);
     hipError_t e = hipGetLastError();

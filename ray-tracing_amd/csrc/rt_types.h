@@ -36,6 +36,8 @@ struct SceneLayout {
 
 #define RT_LEAF 8        // object slots per leaf node (even)
 #define RT_FAN 8         // leaf nodes per top node (even)
+#define RT_SUBQUEUES 32        // interleaved sub-queues of the persistent-wave work queue, one counter each
+#define RT_SUBQUEUE_STRIDE 64   // dwords between two counters (each on its own 256-byte line)
 #define RT_PEND_MAX 16   // pending-ray slots per lane in the global workspace (= RT_MAX_PENDING)
 #define RT_QUEUE 32      // per-ray candidate queue entries (16 bits each, in LDS)
 
@@ -75,7 +77,8 @@ struct KParams {
     int bottom_up;          // output row order
     int part, nparts;       // band split
     int my_bands;           // 16-row bands this part renders
-    unsigned int *work_counter;   // tile queue head of the persistent-wave kernels (zeroed per launch)
+    unsigned int *work_counter;   // queue heads of the persistent-wave kernels: RT_SUBQUEUES counters,
+                                  // RT_SUBQUEUE_STRIDE dwords apart, zeroed ahead of every launch
     int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
     int whole_tiles;              // persistent waves take whole 8x8 tiles only (no per-lane refill)
     float *pend_ws;               // pending-ray workspace: resident_workgroups x RT_PEND_MAX x 11 x 256 floats
