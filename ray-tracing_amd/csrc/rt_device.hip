@@ -1228,7 +1228,6 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (const char *pad = getenv("RT_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
@@ -1294,13 +1293,10 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         // spills for 16 register-resident slots (default scene 4K depth 16 stack 16: 8.9 -> 3.2
         // ms).  With 4-7 slots the register variant wins (0.96 vs 1.65 ms at depth 8 stack 8:
         // a pop from the workspace costs a memory round trip that short iterations cannot hide).
-        static const bool reg_pend = getenv("RT_PEND_REG") != nullptr;     // experiments
-        if (!reg_pend) {
-            KParams kw = kp;
-            kw.whole_tiles = 1;
-            return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
-                         : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
-        }
+        KParams kw = kp;
+        kw.whole_tiles = 1;
+        return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
+                     : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
     }
     if (need <= 3) {
         // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
@@ -1317,7 +1313,7 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         if (!no_ldsp && lds <= 80 * 1024) return RT_LAUNCH(7, true);
         return RT_LAUNCH(7, false);
     }
-    return RT_LAUNCH(16, false);
+    return (int)hipErrorInvalidValue;       // need > 7 returned above
 #undef RT_LAUNCH
 #undef RT_LAUNCH_HIER
 }

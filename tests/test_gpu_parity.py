@@ -338,3 +338,14 @@ def test_large_scene_launches_on_two_streams_do_not_share_the_workspace_at_once(
     torch.cuda.synchronize()
     for b in bufs:
         assert np.array_equal(b.cpu().numpy(), ref)
+
+
+def test_fast_flavour_runs_the_large_scene_kernels(gpu_rt):
+    """The opt-in fast flavour shares the hierarchy / persistent-wave code; on a 200-object scene
+    it must finish and stay close to the strict frame (its tolerance is loose by design)."""
+    scene, cam = gpu_rt.mixed_scene(200, seed=3), gpu_rt.mixed_camera()
+    o = dict(max_depth=6, stack_size=6, shadow_hops=2)
+    strict = gpu_rt.render_rgba(scene, cam, 320, 180, **o).astype(int)
+    fast = gpu_rt.render_rgba(scene, cam, 320, 180, fast_math=True, **o).astype(int)
+    close = np.all(np.abs(fast - strict) <= 1, axis=2).mean()
+    assert close >= 0.85, close        # 50 tori: the fast flavour moves torus pixels (0.936 measured)
