@@ -349,3 +349,22 @@ def test_fast_flavour_runs_the_large_scene_kernels(gpu_rt):
     fast = gpu_rt.render_rgba(scene, cam, 320, 180, fast_math=True, **o).astype(int)
     close = np.all(np.abs(fast - strict) <= 1, axis=2).mean()
     assert close >= 0.85, close        # 50 tori: the fast flavour moves torus pixels (0.936 measured)
+
+
+def test_zz_shutdown_and_reinit_cycle(gpu_rt):
+    """rt_shutdown releases everything and rt_init can be called again (the reference's
+    cleanup + a new App); rendering without a scene after re-init is an error, not a crash."""
+    import ctypes
+    scene, cam = gpu_rt.default_scene(), gpu_rt.default_camera()
+    before = gpu_rt.render_rgba(scene, cam, 96, 64)
+    gpu_rt.shutdown()
+    lib = gpu_rt.init(0)
+    p = gpu_rt.api.make_params(cam, 96, 64)
+    buf = np.zeros((64, 96, 4), dtype=np.uint8)
+    assert lib.rt_render_device(ctypes.addressof(p), buf.ctypes.data, buf.nbytes, None, 0) == -4      # RT_E_STATE: no scene
+    assert b"scene" in lib.rt_last_error()
+    assert np.array_equal(gpu_rt.render_rgba(scene, cam, 96, 64), before)
+    big = gpu_rt.mixed_scene(64)
+    a = gpu_rt.render_rgba(big, gpu_rt.mixed_camera(), 96, 64, max_depth=6, stack_size=6)
+    b = gpu_rt.render_rgba(big, gpu_rt.mixed_camera(), 96, 64, max_depth=6, stack_size=6, no_accel=True)
+    assert np.array_equal(a, b)
