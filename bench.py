@@ -164,6 +164,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # kernel-only view of the same split (no gather, no assemble): max over ranks of the average
+    # render time of this rank's bands, HIP events on the launch stream
+    kernel_only_ms = None
+    if use_dist:
+        k_steps = min(args.steps, 100)
+        barrier()
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(stream)
+        for _ in range(k_steps):
+            render_part(rank, world, pipe.mine[0])
+        k1.record(stream)
+        torch.cuda.synchronize()
+        t = torch.tensor([k0.elapsed_time(k1) / k_steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_only_ms = float(t.item())
+
     result = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -180,6 +196,8 @@ def main():
                        "numerics": "fast" if args.fast_math else "strict (bit-identical to the reference shader)",
                        "tiling": "%d x interleaved 16-row bands, RCCL gather to GPU 0" % world if world > 1 else "single GPU"},
         }
+        if kernel_only_ms is not None:
+            result["kernel_only_ms_per_step"] = kernel_only_ms      # value above includes gather + assemble
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
     if world == 1 and rank == 0 and not force_gather and headline:
