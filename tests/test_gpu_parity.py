@@ -294,7 +294,7 @@ def test_range_restricted_arithmetic_equals_general_forms_exhaustively(gpu_rt):
     assert counts.tolist() == [0, 0, 0, 0]
 
 
-@pytest.mark.parametrize("w,h,nparts", [(203, 117, 3), (64, 40, 2), (333, 31, 5)])
+@pytest.mark.parametrize("w,h,nparts", [(203, 117, 3), (64, 40, 2), (333, 31, 5), (1, 1, 1), (7, 3, 2), (1, 40, 3), (9, 17, 8)])
 def test_persistent_wave_kernel_ragged_sizes_and_band_split(gpu_rt, orc, w, h, nparts):
     """Large scene + deep stack runs the persistent-wave kernel (tile queue, pixel refill):
     sizes that are not multiples of the 8x8 tiles / 16-row bands, whole and split in parts."""
