@@ -54,7 +54,7 @@ def hbm_traffic_bytes(args):
     """HBM bytes per launch of the render kernel as measured with rocprofv3 PMC passes
     (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE; tools/prof_hbm.sh); the summary
     of the latest round under profiles/ is read back, None when there is none for this config."""
-    if args.fast_math or args.stack_size != STACK_SIZE:
+    if args.fast_math or args.stack_size != STACK_SIZE or args.workload != "default4k":
         return None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_4k_d8s3_strict.json")))
@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--fast-math", action="store_true", help="bench the fast flavour instead of the strict one")
     ap.add_argument("--stack-size", type=int, default=None)
     ap.add_argument("--workload", default="default4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--roofline", action="store_true",
+                    help="also for the other workloads: count the frame's events with the instrumented kernel (slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
@@ -200,9 +202,9 @@ def main():
             result["kernel_only_ms_per_step"] = kernel_only_ms      # value above includes gather + assemble
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
-    if world == 1 and rank == 0 and not force_gather and headline:
+    if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
         full = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
-                                     shadow_hops=SHADOW_HOPS, flags=flags)
+                                     shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags)
         import numpy as np
         ev = np.zeros(lib.rt_event_count(), dtype=np.uint64)
         check(lib.rt_count_events(ctypes.addressof(full), ev.ctypes.data))
@@ -219,10 +221,10 @@ def main():
             "traffic": hbm_traffic_bytes(args),
             "kernel": "rt_kernel<%d,false> (%s)" % (tim.pending_cap, "fast" if args.fast_math else "strict"),
             "kernel_ms_avg": kernel_ms, "kernel_ms_single_launch": tim.kernel_ms,
-            "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H),
+            "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H * wl["spp_grid"] ** 2),
             "vgprs": tim.vgprs, "lds_bytes": tim.lds_bytes,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and headline:
             import rt_oracle as orc
             threads = min(os.cpu_count() or 1, 16)
             frames = 0
