@@ -224,6 +224,11 @@ def main():
             "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H * wl["spp_grid"] ** 2),
             "vgprs": tim.vgprs, "lds_bytes": tim.lds_bytes,
         }
+        traffic = result["roofline"]["traffic"]
+        if traffic:
+            # the memory side of the same launch, to show which roof is the near one
+            gbps = traffic / (kernel_ms * 1e-3) / 1e9
+            result["roofline"]["hbm"] = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0}
         if not args.no_cpu_baseline and headline:
             import rt_oracle as orc
             threads = min(os.cpu_count() or 1, 16)
