@@ -239,12 +239,12 @@ def count_events(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=
 
 
 def capture_segment(scene, camera, w, h, seg, *, max_depth=4, stack_size=3, shadow_hops=2, fast_math=False,
-                    bottom_up=True):
+                    bottom_up=True, newton_polish=False):
     """(h, w, 4) float32: object id, t, depth, segment count for segment `seg` of each path."""
     L = _ensure_init()
     set_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
-                    flags=_flags(fast_math, False, bottom_up, False))
+                    flags=_flags(fast_math, newton_polish, bottom_up, False))
     out = np.empty((int(h), int(w), 4), dtype=np.float32)
     _check(L.rt_capture_segment(ctypes.addressof(p), int(seg), out.ctypes.data, out.nbytes))
     return out
