@@ -721,10 +721,13 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // PEND: where the pending-ray slots live: PEND_REG registers (CAP of them, compare/select
 // addressing), PEND_LDS ([slot][field][thread] after the scene), PEND_GLOBAL (same layout in a
 // per-workgroup slice of a global workspace; persistent-wave kernels only, whose grid is
-// bounded by the number of resident workgroups).
-enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2 };
+// bounded by the number of resident workgroups), PEND_HYBRID (the first three slots in LDS,
+// deeper ones in the workspace: most paths never go deeper, and the LDS footprint stays that
+// of the three-slot kernel).
+enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
+#define RT_HYBRID_LDS_SLOTS 3      // PEND_HYBRID: slots 0..2 in LDS, the rest in the global workspace
 template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
-__global__ __launch_bounds__(256, PEND == PEND_LDS ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
+__global__ __launch_bounds__(256, (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
@@ -778,7 +781,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     float accr = 0, accg = 0, accb = 0;                    // sum over samples
     int sample = 0;
     int np = 0;                                            // pending refraction rays
-    constexpr bool LDSP = PEND == PEND_LDS;
+    constexpr bool LDSP = PEND == PEND_LDS || PEND == PEND_HYBRID;
     constexpr bool MEMP = PEND != PEND_REG;             // slots in memory, not registers
     Pending<MEMP ? 1 : CAP> pend;
 #pragma unroll
@@ -788,8 +791,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     }
     // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
     float *pend_lds = lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
-    float *pend_mem = PEND == PEND_GLOBAL ? kp.pend_ws + (size_t)blockIdx.x * (RT_PEND_MAX * 11 * 256) + threadIdx.x
-                                           : pend_lds;
+    float *pend_glb = kp.pend_ws + (size_t)blockIdx.x * (RT_PEND_MAX * 11 * 256) + threadIdx.x;
+    float *pend_mem = PEND == PEND_GLOBAL ? pend_glb : pend_lds;
     (void)LDSP;
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
     unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3)) + threadIdx.x;
@@ -1121,7 +1124,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         float uy = ((thy * omf) * m_transp) * mg;
                         float uz = ((thz * omf) * m_transp) * mb;
                         const int slot = np;
-                        if (MEMP) {
+                        if (PEND == PEND_HYBRID && slot >= RT_HYBRID_LDS_SLOTS) {
+                            float *q = pend_glb + slot * (11 * 256);
+                            q[0 * 256] = qx; q[1 * 256] = qy; q[2 * 256] = qz;
+                            q[3 * 256] = rx; q[4 * 256] = ry; q[5 * 256] = rz;
+                            q[6 * 256] = ux; q[7 * 256] = uy; q[8 * 256] = uz;
+                            q[9 * 256] = n2; q[10 * 256] = __int_as_float(depth + 1);
+                        } else if (MEMP) {
                             float *q = pend_mem + slot * (11 * 256);
                             q[0 * 256] = qx; q[1 * 256] = qy; q[2 * 256] = qz;
                             q[3 * 256] = rx; q[4 * 256] = ry; q[5 * 256] = rz;
@@ -1163,7 +1172,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 WCNT(WP_POP_LOAD);
                 np--;
                 const int slot = np;
-                if (MEMP) {
+                if (PEND == PEND_HYBRID && slot >= RT_HYBRID_LDS_SLOTS) {
+                    const float *q = pend_glb + slot * (11 * 256);
+                    ox = q[0 * 256]; oy = q[1 * 256]; oz = q[2 * 256];
+                    dx = q[3 * 256]; dy = q[4 * 256]; dz = q[5 * 256];
+                    thx = q[6 * 256]; thy = q[7 * 256]; thz = q[8 * 256];
+                    cur_ior = q[9 * 256]; depth = __float_as_int(q[10 * 256]);
+                } else if (MEMP) {
                     const float *q = pend_mem + slot * (11 * 256);
                     ox = q[0 * 256]; oy = q[1 * 256]; oz = q[2 * 256];
                     dx = q[3 * 256]; dy = q[4 * 256]; dz = q[5 * 256];
@@ -1218,14 +1233,15 @@ template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
-    constexpr bool LDSP = PEND == PEND_LDS;
+    constexpr bool LDSP = PEND == PEND_LDS || PEND == PEND_HYBRID;
     static_assert(!(LDSP && HIER), "the LDS pending slots and the candidate queue share one region");
-    static_assert(PEND != PEND_GLOBAL || REFILL, "the global pending-ray workspace is sliced by persistent workgroup");
-    if (PEND == PEND_GLOBAL && !kp.pend_ws) return (int)hipErrorInvalidValue;
+    static_assert((PEND != PEND_GLOBAL && PEND != PEND_HYBRID) || REFILL,
+                  "the global pending-ray workspace is sliced by persistent workgroup");
+    if ((PEND == PEND_GLOBAL || PEND == PEND_HYBRID) && !kp.pend_ws) return (int)hipErrorInvalidValue;
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
-    if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)CAP * 11 * 256 * 4;
+    if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * 256 * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     static bool attr_set = false;
@@ -1287,33 +1303,22 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         // 147 / 168 / 256 for 3 / 7 / 16), measured 1.06-1.46x faster than register slots
         return RT_LAUNCH_HIER(RT_PEND_MAX, PEND_GLOBAL);
     }
-    if (need > 7) {
-        // Small scene, very deep stack: persistent waves that take whole tiles (lanes stay in
-        // lock-step) with the pending rays in the global workspace, 123 VGPRs instead of 256 +
-        // spills for 16 register-resident slots (default scene 4K depth 16 stack 16: 8.9 -> 3.2
-        // ms).  With 4-7 slots the register variant wins (0.96 vs 1.65 ms at depth 8 stack 8:
-        // a pop from the workspace costs a memory round trip that short iterations cannot hide).
+    if (need > 3) {
+        // Small scene, more than three pending rays possible: persistent waves that take whole
+        // tiles (lanes stay in lock-step), slots 0-2 in LDS and the deeper ones in the global
+        // workspace.  Keeps the 34 KB / 4-waves-per-SIMD footprint of the three-slot kernel
+        // (default scene 4K: depth 8 stack 8 0.60 ms, against 0.91 with seven LDS slots at two
+        // workgroups per CU and 0.96 with seven register slots; depth 16 stack 16 2.8 ms
+        // against 8.9 with sixteen register slots).
         KParams kw = kp;
         kw.whole_tiles = 1;
-        return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
-                     : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
+        return multi ? launch_variant<RT_PEND_MAX, false, PEND_HYBRID, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
+                     : launch_variant<RT_PEND_MAX, false, PEND_HYBRID, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
     }
-    if (need <= 3) {
-        // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per
-        // CU next to a small scene, and frees the registers for a fourth wave per SIMD
-        size_t lds = (size_t)kp.scene.total_dwords * 4 + 3 * 11 * 256 * 4;
-        if (!no_ldsp && lds <= 40 * 1024) return RT_LAUNCH(3, true);
-        return RT_LAUNCH(3, false);
-    }
-    if (need <= 7) {
-        // 7 slots in LDS = 77 KB per workgroup: two workgroups per CU, the same 2 waves per SIMD
-        // the 191-VGPR register variant reaches, without its compare/select addressing
-        // (4K depth 8 stack 8: 0.96 -> 0.91 ms)
-        size_t lds = (size_t)kp.scene.total_dwords * 4 + 7 * 11 * 256 * 4;
-        if (!no_ldsp && lds <= 80 * 1024) return RT_LAUNCH(7, true);
-        return RT_LAUNCH(7, false);
-    }
-    return (int)hipErrorInvalidValue;       // need > 7 returned above
+    // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup: fits 4 workgroups per CU
+    // next to a small scene, and frees the registers for a fourth wave per SIMD
+    if (!no_ldsp) return RT_LAUNCH(3, true);
+    return RT_LAUNCH(3, false);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_HIER
 }
