@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Soak run: many seeded large random scenes, accelerated kernels against the plain per-object
+loop (float32 frames must be identical).  usage: tools/soak_large.py first_seed last_seed"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+import numpy as np
+import rt355
+a, b = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(a, b):
+    scene, cam, o = rt355.random_large_scene(seed)
+    w, h = 160 + 8 * (seed % 7), 90 + 5 * (seed % 5)
+    spp = 2 if seed % 4 == 0 else 1
+    x = rt355.render_rgba(scene, cam, w, h, out_f32=True, spp_grid=spp, **o)
+    y = rt355.render_rgba(scene, cam, w, h, out_f32=True, spp_grid=spp, no_accel=True, **o)
+    same = np.array_equal(np.where(np.isnan(x), np.float32(7), x), np.where(np.isnan(y), np.float32(7), y))
+    bad += not same
+    print(seed, len(scene), o, w, h, spp, "ok" if same else "MISMATCH", flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
