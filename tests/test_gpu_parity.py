@@ -9,6 +9,7 @@ primary ray passes the torus bounding sphere is a stated exclusion), and colour 
 1/255 per channel on >= 99.9 % of the pixels outside the exclusion and >= 99 % of all.
 """
 import hashlib
+import os
 
 
 import numpy as np
@@ -222,7 +223,7 @@ def test_4k_headline_properties(gpu_rt):
     assert t["kernel_ms"] > 0 and t["pending_cap"] == 3
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_TEST_SEEDS", "12"))))     # RT_TEST_SEEDS=N: soak run
 def test_random_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
     scene, cam, o = gpu_rt.random_scene(seed)
     n = len(scene)
