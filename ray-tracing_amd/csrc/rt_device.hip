@@ -769,6 +769,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         px = 0; packed_row = 0; gy = 0; active = false;
     }
 
+    // SYNC: with several samples per pixel and one pixel per lane, a lane that has finished a
+    // sample waits for the rest of its wave before it starts the next one: lanes that run ahead
+    // leave lock-step and then every code block of the loop executes on every iteration
+    constexpr bool SYNC = MULTI && !REFILL && !DEBUG;
+    bool parked = false;
     const int N = MULTI ? kp.spp : 1;
     const int nsamples = N * N;
     const float inv_spp = 1.0f / (float)nsamples;
@@ -857,7 +862,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 
     for (;;) {
         if (!REFILL) {
-            if (!active) break;
+            if (SYNC) {
+                // lanes start sample k+1 together, once the whole wave has finished sample k
+                if (__ballot(active && !parked) == 0ull) {
+                    if (__ballot(active) == 0ull) break;
+                    if (active) { start_sample(); parked = false; }
+                }
+            } else if (!active) break;
         } else {
             const unsigned long long need = __ballot(!active);
             // whole_tiles: pixels are handed out only when the whole wave is idle, i.e. a wave
@@ -919,6 +930,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // would let them spin in a loop of their own while the busy lanes wait to reconverge).
         do {
         if (REFILL && !active) break;
+        if (SYNC && (!active || parked)) break;
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
         if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
@@ -1202,7 +1214,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     sample++;
                     si++;
                     if (si == N) { si = 0; sj++; }
-                    if (sample < nsamples) start_sample();
+                    if (sample < nsamples) { if (SYNC) parked = true; else start_sample(); }
                     else active = false;
                 } else {
                     active = false;
