@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_MAX_OBJECTS 1024   /* scene objects per frame (LDS-resident)                 */
+#define RT_MAX_OBJECTS 1024   /* scene objects per frame                                 */
 #define RT_MAX_PENDING 16     /* min(stack_size, max_depth-1) must not exceed this       */
 #define RT_BAND_ROWS   16     /* rows per screen band when a frame is split over GPUs    */
 
@@ -88,7 +88,7 @@ typedef struct rt_timing {
     float kernel_ms;            /* last render kernel, hipEvent-timed on its stream               */
     float total_ms;             /* last rt_render call incl. upload and read-back (host clock)    */
     int32_t vgprs, lds_bytes;   /* resources of the kernel variant that ran                       */
-    int32_t pending_cap;        /* register-resident pending-ray slots of that variant            */
+    int32_t pending_cap;        /* pending-ray slots per lane of that variant (LDS / workspace)   */
 } rt_timing;
 
 /* Replaces context/program creation (main.py:134-161, :195-208): binds the process to

@@ -94,7 +94,7 @@ int validate_params(const rt_params *p)
     if (p->spp_grid < 1 || p->spp_grid > 16) return fail(RT_E_LIMIT, "spp_grid must be 1..16");
     int need = p->stack_size < p->max_depth - 1 ? p->stack_size : p->max_depth - 1;
     if (need > RT_MAX_PENDING)
-        return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d register-resident pending rays",
+        return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d pending-ray slots per lane",
                     need, RT_MAX_PENDING);
     if (p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return fail(RT_E_ARG, "bad part/nparts");
     for (int i = 0; i < 16; ++i)
