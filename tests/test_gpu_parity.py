@@ -369,3 +369,18 @@ def test_zz_shutdown_and_reinit_cycle(gpu_rt):
     a = gpu_rt.render_rgba(big, gpu_rt.mixed_camera(), 96, 64, max_depth=6, stack_size=6)
     b = gpu_rt.render_rgba(big, gpu_rt.mixed_camera(), 96, 64, max_depth=6, stack_size=6, no_accel=True)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["spheres256_d16", "mixed1024_16spp", "tori64_d8s8"])
+def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
+    """The big configurations at larger sizes (a few seconds of CPU oracle time on the GPU box's
+    cores)."""
+    if which == "spheres256_d16":
+        scene, cam, w, h, o = gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 640, 360, dict(max_depth=16, stack_size=16, shadow_hops=4)
+    elif which == "mixed1024_16spp":
+        scene, cam, w, h, o = gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera(), 384, 216, dict(max_depth=8, stack_size=8, shadow_hops=2, spp_grid=4)
+    else:
+        scene, cam, w, h, o = gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera(), 960, 540, dict(max_depth=8, stack_size=8, shadow_hops=2)
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, want_f32=True, **o)["f32"]
+    assert f32_identical(f32, ref)
