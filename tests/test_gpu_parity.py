@@ -381,6 +381,8 @@ def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
         scene, cam, w, h, o = gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera(), 384, 216, dict(max_depth=8, stack_size=8, shadow_hops=2, spp_grid=4)
     else:
         scene, cam, w, h, o = gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera(), 960, 540, dict(max_depth=8, stack_size=8, shadow_hops=2)
+    if os.environ.get("RT_HEAVY_FULL") == "1":       # one-off: the full benchmark sizes (minutes of CPU time)
+        w, h = (1920, 1080) if which == "mixed1024_16spp" else (3840, 2160)
     f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
     ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, want_f32=True, **o)["f32"]
     assert f32_identical(f32, ref)
