@@ -150,10 +150,10 @@ int rt_stage_scene_host(const rt_object *objs, int n, float *blob, size_t blob_d
 /* Self-test of the strict flavour's arithmetic (no counterpart in the reference, whose sqrt
  * and division are the CPU's): the kernels run range-restricted forms of the correctly rounded
  * sqrt, 1/sqrt and division; this compares them on the GPU with the general forms over every
- * binary32 operand of their ranges (about 4.8e9 evaluations, well under a second).
- * counts[i] = operands whose results differ: sqrt, 1/sqrt, reciprocal, log2's quotient.
- * All four must be 0.                                                                     */
-int rt_selftest_math(uint64_t counts[4]);
+ * binary32 operand of their ranges (about 1.3e10 evaluations, about a second).
+ * counts[i] = operands whose results differ: sqrt, 1/sqrt, reciprocal, log2's quotient,
+ * x / 3, x / 27.  All six must be 0.                                                       */
+int rt_selftest_math(uint64_t counts[6]);
 
 #ifdef __cplusplus
 }

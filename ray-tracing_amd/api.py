@@ -267,10 +267,10 @@ def stage_scene_host(scene):
 
 
 def selftest_math():
-    """Mismatch counts (sqrt, 1/sqrt, reciprocal, log2 quotient) of the strict flavour's
-    range-restricted arithmetic against the general forms, over all operands; all 0."""
+    """Mismatch counts (sqrt, 1/sqrt, reciprocal, log2 quotient, x/3, x/27) of the strict
+    flavour's range-restricted arithmetic against the general forms, over all operands; all 0."""
     L = _ensure_init()
-    counts = np.zeros(4, dtype=np.uint64)
+    counts = np.zeros(6, dtype=np.uint64)
     _check(L.rt_selftest_math(counts.ctypes.data))
     return counts
 

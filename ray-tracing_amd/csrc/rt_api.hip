@@ -554,20 +554,20 @@ int rt_get_timing(rt_timing *t)
     return RT_OK;
 }
 
-int rt_selftest_math(uint64_t counts[4])
+int rt_selftest_math(uint64_t counts[6])
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
     if (!counts) return fail(RT_E_ARG, "counts is null");
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 4 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), g.stream);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 6 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 6 * sizeof(unsigned long long), g.stream);
     if (e == hipSuccess) e = (hipError_t)rt_strict::launch_selftest(d, g.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RT_E_HIP, "math self-test: %s", hipGetErrorString(e));
-    for (int i = 0; i < 4; ++i) counts[i] = h[i];
+    for (int i = 0; i < 6; ++i) counts[i] = h[i];
     return RT_OK;
 }
 

@@ -50,6 +50,7 @@ DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
 DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
+template <int C> DEV float rt_div_const(float x) { return x * (1.0f / (float)C); }
 #else
 // strict flavour: correctly rounded, as the reference's CPU GL computes them.
 //
@@ -96,6 +97,24 @@ DEV float div_core(float a, float b)
     q = __builtin_fmaf(r0, y, q);
     float r1 = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(r1, y, q);
+}
+// x / 3 and x / 27 (the cubic's constants, :201-215) for |x| in [2^-96, 2^96): product with the
+// rounded reciprocal, exact remainder, one correction.  For these two divisors the sequence
+// returns the correctly rounded quotient for every such x (rt_selftest_kernel checks all of
+// them against the general division).
+template <int C> DEV float div_const_core(float x)
+{
+    constexpr float c = (float)C;
+    constexpr float rc = C == 3 ? 0x1.555556p-2f : 0x1.2f684cp-5f;     // RN(1/3), RN(1/27)
+    float q = x * rc;
+    float r = __builtin_fmaf(-c, q, x);
+    return __builtin_fmaf(r, rc, q);
+}
+DEV bool div_const_in_core_range(float x) { return ((f_bits(x) & 0x7fffffffu) - 0x0f800000u) < 0x60000000u; }
+template <int C> DEV float rt_div_const(float x)
+{
+    if (div_const_in_core_range(x)) return div_const_core<C>(x);
+    return x / (float)C;
 }
 // binary32 patterns 0x0f800000 .. 0x6f7fffff are the positive numbers in [2^-96, 2^96)
 DEV bool sqrt_in_core_range(float x) { return (f_bits(x) - 0x0f800000u) < 0x60000000u; }
@@ -308,12 +327,12 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
         float bn = p * p - 4.0f * r;
         float cn = -(q * q);
         float an2 = an * an;
-        float pc = bn - rt_div(an2, 3.0f);
-        float off_c = rt_div(an, 3.0f);
-        float qc = (cn - rt_div(an * bn, 3.0f)) + rt_div((2.0f * an2) * an, 27.0f);
+        float pc = bn - rt_div_const<3>(an2);
+        float off_c = rt_div_const<3>(an);
+        float qc = (cn - rt_div_const<3>(an * bn)) + rt_div_const<27>((2.0f * an2) * an);
         float half_q = 0.5f * qc;
         float p3 = (pc * pc) * pc;
-        float disc = half_q * half_q + rt_div(p3, 27.0f);
+        float disc = half_q * half_q + rt_div_const<27>(p3);
         float u;
         if (disc >= -Q_EPS) {
             CNT(EV_CARDANO);
@@ -326,12 +345,12 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
             u = (rootA - off_c) + rootB;
         } else {
             CNT(EV_TRIG);
-            float rho = rt_sqrt(rt_div(-p3, 27.0f));
+            float rho = rt_sqrt(rt_div_const<27>(-p3));
             float x = rt_div(-half_q, rho);
             x = (x > -1.0f) ? x : -1.0f;       // NaN -> -1
             x = (x < 1.0f) ? x : 1.0f;
-            float theta = rt_div(rt_acos(x), 3.0f);
-            float m = 2.0f * rt_sqrt(rt_div(-pc, 3.0f));
+            float theta = rt_div_const<3>(rt_acos(x));
+            float m = 2.0f * rt_sqrt(rt_div_const<3>(-pc));
             u = m * rt_cos(theta) - off_c;
         }
         if (!(u < 0.0f)) {
@@ -1347,7 +1366,8 @@ int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_
 // compiler's full expansions.  counts[0]: sqrt over all x in [2^-96, 2^96); counts[1]:
 // 1/sqrt over the same x; counts[2]: 1/s over all s in [2^-48, 2^48]; counts[3]: log2's
 // (m - 1)/(m + 1) over all m in [1, 2).  A count is the number of operands whose results
-// differ in any bit.
+// differ in any bit.  counts[4], counts[5]: x / 3 and x / 27 over all x of both signs with |x|
+// in [2^-96, 2^96).
 __global__ __launch_bounds__(256) void rt_selftest_kernel(unsigned long long *counts)
 {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
@@ -1372,6 +1392,21 @@ __global__ __launch_bounds__(256) void rt_selftest_kernel(unsigned long long *co
         float m = bits_f(u);
         bad3 += f_bits(div_core(m - 1.0f, m + 1.0f)) != f_bits((m - 1.0f) / (m + 1.0f));
     }
+    unsigned int bad4 = 0, bad5 = 0;
+    for (uint32_t u = 0x0f800000u + tid; u < 0x6f800000u; u += stride) {
+        for (uint32_t sign = 0; sign < 2; ++sign) {
+            float x = bits_f(u | (sign << 31));
+            bad4 += f_bits(div_const_core<3>(x)) != f_bits(x / 3.0f);
+            bad5 += f_bits(div_const_core<27>(x)) != f_bits(x / 27.0f);
+            bad4 += !div_const_in_core_range(x);
+        }
+    }
+    if (tid == 0)
+        bad4 += div_const_in_core_range(0.0f) + div_const_in_core_range(-0.0f) + div_const_in_core_range(bits_f(0x0f7fffffu)) +
+                div_const_in_core_range(bits_f(0xef800000u)) + div_const_in_core_range(bits_f(0x7f800000u)) +
+                div_const_in_core_range(bits_f(0xffc00000u)) + div_const_in_core_range(bits_f(0x80000001u));
+    if (bad4) atomicAdd(&counts[4], (unsigned long long)bad4);
+    if (bad5) atomicAdd(&counts[5], (unsigned long long)bad5);
     if (bad0) atomicAdd(&counts[0], (unsigned long long)bad0);
     if (bad1) atomicAdd(&counts[1], (unsigned long long)bad1);
     if (bad2) atomicAdd(&counts[2], (unsigned long long)bad2);
