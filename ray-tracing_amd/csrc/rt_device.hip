@@ -725,18 +725,18 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 #ifndef RT_WAVES_PER_EU_LDSP
 #define RT_WAVES_PER_EU_LDSP 4
 #endif
-// LDSP: the pending-ray slots live in LDS ([slot][field][thread], one conflict-free dword
-// column per lane) instead of registers; used where that buys a wave of occupancy.
+// Template flags of the kernel:
 // MULTI: more than one sample per pixel (sample loop + accumulators); the single-sample
 // kernel carries neither.
-// HIER: trace through the sphere hierarchy (large scenes); the candidate queue follows the
-// scene in LDS.
-// REFILL: persistent waves with a work queue (deep recursion).  The frame is a queue of 8x8
-// tiles behind one global counter; a wave takes a tile, and whenever lanes finish their pixel
-// they are handed the next unassigned pixels of the wave's current tile (ballot + prefix
+// HIER: trace through the sphere hierarchy (large scenes); only the hierarchy sections and the
+// per-lane candidate queues are in LDS, the rest of the scene is read from global memory.
+// REFILL: persistent waves behind a work queue.  The frame is a queue of 8x8 tiles in
+// RT_SUBQUEUES interleaved sub-queues; a wave takes a tile, and whenever lanes finish their
+// pixel they are handed the next unassigned pixels of the wave's current tile (ballot + prefix
 // count), a new tile being taken when it runs out.  Path-tree sizes differ by orders of
 // magnitude between neighbouring pixels at depth 16, so without this most lanes of a wave
-// wait for its longest pixel.
+// wait for its longest pixel.  With kp.whole_tiles the pixels are handed out only when the
+// whole wave is idle: tile after tile with the lanes in lock-step (small scenes).
 // PEND: where the pending-ray slots live: PEND_REG registers (CAP of them, compare/select
 // addressing), PEND_LDS ([slot][field][thread] after the scene), PEND_GLOBAL (same layout in a
 // per-workgroup slice of a global workspace; persistent-wave kernels only, whose grid is
