@@ -1334,6 +1334,14 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         // 147 / 168 / 256 for 3 / 7 / 16), measured 1.06-1.46x faster than register slots
         return RT_LAUNCH_HIER(RT_PEND_MAX, PEND_GLOBAL);
     }
+    if ((size_t)kp.scene.total_dwords * 4 + 3 * 11 * 256 * 4 > 150 * 1024) {
+        // per-object loop forced on a scene whose blob leaves no LDS for pending slots
+        // (RT_FLAG_NO_ACCEL with ~1000 tori): all slots in the workspace
+        KParams kw = kp;
+        kw.whole_tiles = 1;
+        return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
+                     : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
+    }
     if (need > 3) {
         // Small scene, more than three pending rays possible: persistent waves that take whole
         // tiles (lanes stay in lock-step), slots 0-2 in LDS and the deeper ones in the global

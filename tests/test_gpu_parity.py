@@ -386,3 +386,14 @@ def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
     f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
     ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, want_f32=True, **o)["f32"]
     assert f32_identical(f32, ref)
+
+
+def test_largest_scene_blob_with_and_without_the_hierarchy(gpu_rt):
+    """1024 tori = the largest blob (139 KB): the forced per-object loop has no LDS left for
+    pending slots and must still run (workspace slots) and agree with the hierarchy kernels."""
+    scene = gpu_rt.tori_stress_scene(1024, seed=5)
+    cam = gpu_rt.tori_stress_camera()
+    for o in (dict(max_depth=3, stack_size=2, shadow_hops=1), dict(max_depth=6, stack_size=6, shadow_hops=1)):
+        a = gpu_rt.render_rgba(scene, cam, 64, 36, out_f32=True, **o)
+        b = gpu_rt.render_rgba(scene, cam, 64, 36, out_f32=True, no_accel=True, **o)
+        assert f32_identical(a, b), o
