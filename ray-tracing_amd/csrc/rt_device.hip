@@ -9,22 +9,30 @@
 // Both are the same source; the flavour only changes the primitives in the "numerics" block.
 //
 // Design (wave64, VALU-bound, no MFMA: there is no dense contraction in this workload):
-//   * one lane = one pixel; a wave owns an 8x8 pixel tile, a 256-thread workgroup 16x16.
+//   * one lane = one pixel at a time; a wave owns an 8x8 pixel tile.  Small scenes: one tile per
+//     wave and launch, 256-thread workgroup = 16x16 pixels.  Large scenes and deep stacks:
+//     persistent waves that take tiles from a work queue (REFILL below).
 //   * the scene is staged once per workgroup in LDS, split so that the per-object hot loop
 //     reads one 16-byte record (centre + bounding radius^2) as an LDS broadcast; torus
 //     frames, kinds and materials sit behind the bounding test / the closest-hit decision.
+//     Scenes of 40+ objects are traced through a sphere hierarchy that returns exactly the
+//     per-object loop's hits (rt_intersect.h).
 //   * trace() keeps only (t, id) of the closest hit; position, normal and material are
 //     derived once for the winner (the reference builds a full HitInfo per candidate,
 //     fragment_shader.glsl:416-425; only the winner's is ever read).
-//   * the reference's explicit ray stack (fragment_shader.glsl:547-564) is held in
-//     registers as "current ray + pending refraction rays": the reflection child is always
-//     popped right after it is pushed, so it never needs a slot; slots are addressed with
-//     compare/select chains (no dynamic register indexing, no scratch memory).  Visit order
-//     and the silent drop rule (stack_ptr < STACK_SIZE, :615/:632) are preserved exactly.
+//   * the reference's explicit ray stack (fragment_shader.glsl:547-564) is "current ray +
+//     pending refraction rays": the reflection child is always popped right after it is
+//     pushed, so it never needs a slot.  The pending slots live in LDS, in a global workspace
+//     or in registers (PEND below).  Visit order and the silent drop rule (stack_ptr <
+//     STACK_SIZE, :615/:632) are preserved exactly.
 //   * path rays and shadow rays go through ONE trace site: each lane is a small state
 //     machine (PATH / SHADOW), so lanes shading and lanes casting shadow rays share the
 //     wave's trace iterations instead of serialising two inlined copies of trace().
-//   * a lane that finishes a sample starts its next stratified sample immediately.
+//   * lanes of a wave are kept in lock-step wherever path lengths allow it (whole tiles, samples
+//     started together): when lanes drift apart every code block of the loop runs on every
+//     iteration, which costs more than the idle lanes it saves -- except at depth 16 on large
+//     scenes, where per-lane pixel refill wins.
+// The arithmetic primitives are in rt_numerics.h, intersection and trace in rt_intersect.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -37,672 +45,12 @@
 #define RT_NS rt_strict
 #endif
 
-namespace RT_NS {
-
-// ------------------------------------------------------------------ numerics
 #define DEV __device__ __forceinline__
 
-DEV float bits_f(uint32_t u) { return __uint_as_float(u); }
-DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
+#include "rt_numerics.h"
+#include "rt_intersect.h"
 
-#ifdef RT_FAST
-// fast flavour: hardware reciprocal / rsqrt / sqrt (1 ulp), FMA contraction (compile flag)
-DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
-DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
-template <int C> DEV float rt_div_const(float x) { return x * (1.0f / (float)C); }
-#else
-// strict flavour: correctly rounded, as the reference's CPU GL computes them.
-//
-// The compiler's expansions of sqrt and of division spend a third of their instructions on
-// operand scaling and on the special values (0, inf, NaN, results near the denormal range).
-// For operands well inside the normal range those steps are identities, so the functions
-// below run the same refinement sequences without them -- the same instructions in the same
-// order, hence the same bits -- and leave every other operand to the compiler's expansion.
-// rt_selftest_kernel compares both forms over every binary32 operand of the guarded ranges.
-DEV float rt_div(float a, float b) { return a / b; }
-
-// sqrt for x in [2^-96, 2^96): rsq seed, one coupled Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)),
-// one residual correction
-DEV float sqrt_core(float x)
-{
-    float r = __builtin_amdgcn_rsqf(x);
-    float g = x * r;
-    float h = 0.5f * r;
-    float e = __builtin_fmaf(-h, g, 0.5f);
-    g = __builtin_fmaf(g, e, g);
-    float d = __builtin_fmaf(-g, g, x);
-    h = __builtin_fmaf(h, e, h);
-    return __builtin_fmaf(d, h, g);
-}
-// 1/s for s in [2^-48, 2^48]: rcp seed, Newton step, two residual corrections of the quotient
-DEV float rcp_core(float s)
-{
-    float y = __builtin_amdgcn_rcpf(s);
-    float e = __builtin_fmaf(-s, y, 1.0f);
-    y = __builtin_fmaf(e, y, y);
-    float r0 = __builtin_fmaf(-s, y, 1.0f);
-    float q = __builtin_fmaf(r0, y, y);
-    float r1 = __builtin_fmaf(-s, q, 1.0f);
-    return __builtin_fmaf(r1, y, q);
-}
-// a / b for b in [2^-48, 2^48] and a == 0 or |a| in [2^-48, 2^48]
-DEV float div_core(float a, float b)
-{
-    float y = __builtin_amdgcn_rcpf(b);
-    float e = __builtin_fmaf(-b, y, 1.0f);
-    y = __builtin_fmaf(e, y, y);
-    float q = a * y;
-    float r0 = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(r0, y, q);
-    float r1 = __builtin_fmaf(-b, q, a);
-    return __builtin_fmaf(r1, y, q);
-}
-// x / 3 and x / 27 (the cubic's constants, :201-215) for |x| in [2^-96, 2^96): product with the
-// rounded reciprocal, exact remainder, one correction.  For these two divisors the sequence
-// returns the correctly rounded quotient for every such x (rt_selftest_kernel checks all of
-// them against the general division).
-template <int C> DEV float div_const_core(float x)
-{
-    constexpr float c = (float)C;
-    constexpr float rc = C == 3 ? 0x1.555556p-2f : 0x1.2f684cp-5f;     // RN(1/3), RN(1/27)
-    float q = x * rc;
-    float r = __builtin_fmaf(-c, q, x);
-    return __builtin_fmaf(r, rc, q);
-}
-DEV bool div_const_in_core_range(float x) { return ((f_bits(x) & 0x7fffffffu) - 0x0f800000u) < 0x60000000u; }
-template <int C> DEV float rt_div_const(float x)
-{
-    if (div_const_in_core_range(x)) return div_const_core<C>(x);
-    return x / (float)C;
-}
-// binary32 patterns 0x0f800000 .. 0x6f7fffff are the positive numbers in [2^-96, 2^96)
-DEV bool sqrt_in_core_range(float x) { return (f_bits(x) - 0x0f800000u) < 0x60000000u; }
-DEV float rt_sqrt(float a)
-{
-    if (sqrt_in_core_range(a)) return sqrt_core(a);
-    return __builtin_sqrtf(a);
-}
-DEV float rt_rsq(float a)
-{
-    if (sqrt_in_core_range(a)) return rcp_core(sqrt_core(a));
-    return 1.0f / __builtin_sqrtf(a);
-}
-#endif
-
-// pow(x, y) = exp2(y * log2 x) with the polynomial kernels the reference's CPU GL runs
-// (mantissa/exponent split + degree-4 minimax in ((m-1)/(m+1))^2; floor/fraction split +
-// degree-5 minimax), multiply-adds fused.  Both flavours use them: the reference's pow is
-// ~2 ulp off and its acos 7e-5 off, and the torus solver amplifies such differences, so a
-// more accurate pow would move torus pixels away from the reference.
-DEV float lp_log2(float x)
-{
-    uint32_t i = f_bits(x);
-    float e = (float)((int)((i & 0x7f800000u) >> 23) - 127);
-    float m = bits_f((i & 0x007fffffu) | 0x3f800000u);
-#ifdef RT_FAST
-    float y = rt_div(m - 1.0f, m + 1.0f);
-#else
-    float y = div_core(m - 1.0f, m + 1.0f);      // numerator 0 or in [2^-23, 1), denominator in [2, 3)
-#endif
-    float z = y * y;
-    float z2 = z * z;
-    float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f), 0x1.715476p+1f);
-    float odd = __builtin_fmaf(z2, 0x1.9d062cp-2f, 0x1.ec6ff2p-1f);
-    float p = __builtin_fmaf(odd, z, even);
-    float r = __builtin_fmaf(y, p, e);
-    if (x >= __builtin_inff()) r = __builtin_inff();
-    if (x == 0.0f) r = -__builtin_inff();
-    if (!(x >= 0.0f)) r = __builtin_nanf("");
-    return r;
-}
-DEV float rt_pow(float x, float y)
-{
-    if (!(x < 0.0f || x > 0.0f)) return 0.0f;
-    float t = lp_log2(x) * y;              // NaN for x < 0, and NaN passes through the clamps
-    t = (128.0f < t) ? 128.0f : t;
-    t = (-0x1.fbfffep+6f > t) ? -0x1.fbfffep+6f : t;
-    float fl = __builtin_floorf(t);
-    float fpart = t - fl;
-    int ipart = (int)fl;
-    float scale = bits_f((uint32_t)(ipart + 127) << 23);
-    float x2 = fpart * fpart;
-    float odd = __builtin_fmaf(x2, __builtin_fmaf(x2, 0x1.ec320ap-10f, 0x1.c95446p-5f), 0x1.62e4f6p-1f);
-    float even = __builtin_fmaf(x2, __builtin_fmaf(x2, 0x1.26900cp-7f, 0x1.ebd5a8p-3f), 1.0f);
-    float p = __builtin_fmaf(odd, fpart, even);
-    return scale * p;
-}
-// cos(x): octant reduction with a three-part pi/4 and the sin/cos minimax pair.
-DEV float rt_cos(float x)
-{
-    float xa = __builtin_fabsf(x);
-    float sy = xa * 0x1.45f306p+0f;
-    int j = (int)sy;
-    j = (j + 1) & ~1;
-    float yf = (float)j;
-    int emm2 = j - 2;
-    uint32_t sign_bit = ((uint32_t)(~emm2) & 4u) << 29;
-    bool use_sin = (emm2 & 2) == 0;
-    float r = __builtin_fmaf(yf, -0.78515625f, xa);
-    r = __builtin_fmaf(yf, -0x1.fb4p-13f, r);
-    r = __builtin_fmaf(yf, -0x1.4442d2p-25f, r);
-    float z = r * r;
-    float s = __builtin_fmaf(z, -0x1.9943f2p-13f, 0x1.11073cp-7f);
-    s = __builtin_fmaf(s, z, -0x1.555546p-3f);
-    s = s * z;
-    s = __builtin_fmaf(s, r, r);
-    float c = __builtin_fmaf(z, 0x1.99eb9cp-16f, -0x1.6c0c34p-10f);
-    c = __builtin_fmaf(c, z, 0x1.55554ap-5f);
-    c = c * z;
-    c = c * z;
-    c = c - z * 0.5f;
-    c = c + 1.0f;
-    float res = bits_f(f_bits(use_sin ? s : c) ^ sign_bit);
-    if ((f_bits(x) & 0x7f800000u) == 0x7f800000u) return __builtin_nanf("");
-    res = (res < 1.0f) ? res : 1.0f;
-    res = (res > -1.0f) ? res : -1.0f;
-    return res;
-}
-
-// acos as the GLSL front end lowers it (both flavours; it is six cheap ops and a sqrt).
-DEV float rt_acos(float x)
-{
-    const float half_pi = 0x1.921fb6p+0f;
-    float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
-    float ax = __builtin_fabsf(x);
-    float t = rt_sqrt(1.0f - ax);
-    float p = ax * -0x1.8334bep-6f;
-    p = 0x1.4d1b0ep-4f + p;
-    p = ax * p;
-    p = -0x1.b78128p-3f + p;
-    p = ax * p;
-    p = half_pi + p;
-    float q = t * p;
-    q = half_pi - q;
-    q = s * q;
-    return half_pi - q;
-}
-
-DEV float sign_f(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-// max(0, x) with NaN -> 0, as the reference's max(0.0, x) behaves on its CPU GL
-DEV float max0(float x) { return x > 0.0f ? x : 0.0f; }
-// dot product in the reference's summation order: (z + y) + x
-DEV float dot3(float ax, float ay, float az, float bx, float by, float bz)
-{
-    return (az * bz + ay * by) + ax * bx;
-}
-
-// ------------------------------------------------------------------ event counters
-// Two uses of the same LDS counter array in the instrumented flavour: event counts (one per
-// lane and event, the FLOP accounting), or -- wave_mode -- a profile of the code blocks a wave
-// executes (WCNT: once per wave that enters the block with any lane; LCNT: lanes in it).
-template <bool DEBUG> struct Counters {
-    unsigned int *lds_ev;
-    DEV void add(int) const {}
-    DEV void wave(int) const {}
-    DEV void lanes(int) const {}
-};
-template <> struct Counters<true> {
-    unsigned int *lds_ev;
-    int wave_mode;
-    DEV void add(int ev) const { if (!wave_mode) atomicAdd(&lds_ev[ev], 1u); }
-    DEV void wave(int slot) const
-    {
-        if (wave_mode) {
-            unsigned long long m = __ballot(1);
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&lds_ev[slot], 1u);
-        }
-    }
-    DEV void lanes(int slot) const { if (wave_mode) atomicAdd(&lds_ev[slot], 1u); }
-};
-#define CNT(ev) cnt.add(ev)
-#define WCNT(slot) cnt.wave(slot)
-#define LCNT(slot) cnt.lanes(slot)
-enum { WP_ITER, WP_ITER_LANES, WP_PAIR, WP_CAND, WP_CAND_LANES, WP_TBOUND, WP_SPHERE, WP_SPHERE_LANES,
-       WP_SPHERE_ROOT2, WP_TORUS, WP_TORUS_LANES, WP_PLANE_DIV, WP_PATH, WP_PATH_LANES, WP_SKY, WP_HIT,
-       WP_HIT_LANES, WP_NORMAL_SPHERE, WP_NORMAL_TORUS, WP_FRESNEL_POW, WP_FRESNEL_DIV, WP_LOCAL, WP_SHADOW,
-       WP_SHADOW_LANES, WP_SPAWN, WP_SPAWN_LANES, WP_PHONG, WP_PHONG_LANES, WP_CHILDREN, WP_REFR, WP_REFR_PUSH,
-       WP_REFL, WP_POP, WP_POP_LOAD, WP_FINISH, WP_START, WP_COUNT };
-static_assert(WP_COUNT <= EV_COUNT, "the wave profile shares the event counter array");
-
-// ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
-#define Q_EPS 1e-7f
-
-struct RootMin {
-    float t; bool found;
-    DEV void offer(float r) { if (r > 0.001f && r < t) { t = r; found = true; } }
-};
-
-// solve_quadratic (:159-180) for the monic calls of solve_quartic: a = 1.
-// bb is b*b as the compiled reference has it.  Offers (root - offset) to `rm`.
-template <bool DEBUG>
-DEV void quad_monic_offer(float bb, float b, float c, float offset, RootMin &rm, const Counters<DEBUG> &cnt)
-{
-    float disc = bb - 4.0f * c;
-    if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); return; }
-    CNT(EV_QUAD_FULL);
-    disc = max0(disc);
-    float sq = rt_sqrt(disc);
-    CNT(EV_ROOT_OUT);
-    rm.offer((-b + sq) * 0.5f - offset);
-    if (!(disc < Q_EPS)) { CNT(EV_ROOT_OUT); rm.offer((-b - sq) * 0.5f - offset); }
-}
-
-// Smallest root > 0.001 of t^4 + A t^3 + B t^2 + C t + D (Ferrari, :250-305 + :345-352).
-template <bool DEBUG>
-DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const Counters<DEBUG> &cnt)
-{
-    float a2 = a * a;
-    float p = b - 0.375f * a2;
-    float q = (c - (0.5f * a) * b) + (0.125f * a2) * a;
-    float r = ((d - (0.25f * a) * c) + (0.0625f * a2) * b) - (0.01171875f * a2) * a2;
-    float offset = 0.25f * a;
-    RootMin rm; rm.t = 1e20f; rm.found = false;
-    if (__builtin_fabsf(q) < Q_EPS) {
-        // biquadratic (:262-276): quadratic in y^2
-        float disc = p * p - 4.0f * r;
-        if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); }
-        else {
-            CNT(EV_QUAD_FULL);
-            disc = max0(disc);
-            float sq = rt_sqrt(disc);
-            int ny = disc < Q_EPS ? 1 : 2;
-            float z0 = (-p + sq) * 0.5f, z1 = (-p - sq) * 0.5f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float z = i == 0 ? z0 : z1;
-                if (i < ny && z >= -Q_EPS) {
-                    CNT(EV_BIQ_Z);
-                    float y = rt_sqrt(max0(z));
-                    CNT(EV_ROOT_OUT);
-                    rm.offer(y - offset);
-                    if (y > Q_EPS) { CNT(EV_ROOT_OUT); rm.offer(-y - offset); }
-                }
-            }
-        }
-    } else {
-        // resolvent cubic u^3 + 2p u^2 + (p^2 - 4r) u - q^2 (:281), first root only (:285)
-        CNT(EV_CUBIC);
-        float an = 2.0f * p;
-        float bn = p * p - 4.0f * r;
-        float cn = -(q * q);
-        float an2 = an * an;
-        float pc = bn - rt_div_const<3>(an2);
-        float off_c = rt_div_const<3>(an);
-        float qc = (cn - rt_div_const<3>(an * bn)) + rt_div_const<27>((2.0f * an2) * an);
-        float half_q = 0.5f * qc;
-        float p3 = (pc * pc) * pc;
-        float disc = half_q * half_q + rt_div_const<27>(p3);
-        float u;
-        if (disc >= -Q_EPS) {
-            CNT(EV_CARDANO);
-            disc = max0(disc);
-            float sq = rt_sqrt(disc);
-            float A = -half_q + sq;
-            float B = -half_q - sq;
-            float rootA = sign_f(A) * rt_pow(__builtin_fabsf(A), 0x1.555556p-2f);
-            float rootB = sign_f(B) * rt_pow(__builtin_fabsf(B), 0x1.555556p-2f);
-            u = (rootA - off_c) + rootB;
-        } else {
-            CNT(EV_TRIG);
-            float rho = rt_sqrt(rt_div_const<27>(-p3));
-            float x = rt_div(-half_q, rho);
-            x = (x > -1.0f) ? x : -1.0f;       // NaN -> -1
-            x = (x < 1.0f) ? x : 1.0f;
-            float theta = rt_div_const<3>(rt_acos(x));
-            float m = 2.0f * rt_sqrt(rt_div_const<3>(-pc));
-            u = m * rt_cos(theta) - off_c;
-        }
-        if (!(u < 0.0f)) {
-            CNT(EV_FERRARI_TAIL);
-            float w = rt_sqrt(u);
-            float term_A = 0.5f * (p + u);
-            float term_B = rt_div(0.5f * q, w + Q_EPS);
-            float bb = __builtin_fabsf(u);
-            quad_monic_offer<DEBUG>(bb, w, term_A - term_B, offset, rm, cnt);
-            quad_monic_offer<DEBUG>(bb, -w, term_A + term_B, offset, rm, cnt);
-        }
-    }
-    t_out = rm.t;
-    return rm.found;
-}
-
-struct TorusFrame { float ux, uy, uz, wx, wy, wz, vx, vy, vz, R, R2, r2, fourR2, eightR2; };
-
-DEV TorusFrame load_torus(const float *lds, int off_torus, int slot)
-{
-    const float4 *q = reinterpret_cast<const float4 *>(lds + off_torus + 16 * slot);
-    float4 a = q[0], b = q[1], c = q[2], d = q[3];
-    TorusFrame f;
-    f.ux = a.x; f.uy = a.y; f.uz = a.z; f.wx = a.w;
-    f.wy = b.x; f.wz = b.y; f.vx = b.z; f.vy = b.w;
-    f.vz = c.x; f.R = c.y; f.R2 = c.z; f.r2 = c.w;
-    f.fourR2 = d.x; f.eightR2 = d.y;
-    return f;
-}
-
-// Two Newton steps on the selected root; kept only if the residual shrinks.
-DEV float newton_polish(float A, float B, float C, float D, float t)
-{
-    float t0 = t;
-    float f0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t, 1.0f, A), t, B), t, C), t, D);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        float f = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
-        float df = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(4.0f, t, 3.0f * A), t, 2.0f * B), t, C);
-        float step = f * __builtin_amdgcn_rcpf(df);
-        t = t - step;
-    }
-    float f1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
-    bool ok = __builtin_fabsf(f1) < __builtin_fabsf(f0) && t > 0.001f;
-    return ok ? t : t0;
-}
-
-// intersect_torus (:309-352) up to the root; ocx.. = ray origin - centre.
-template <bool DEBUG>
-DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, float dx, float dy, float dz,
-                       int polish, float &t_out, const Counters<DEBUG> &cnt)
-{
-    CNT(EV_TORUS_CALL);
-    float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
-    float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
-    float roz = dot3(ocx, ocy, ocz, f.vx, f.vy, f.vz);
-    float rdx = dot3(dx, dy, dz, f.ux, f.uy, f.uz);
-    float rdy = dot3(dx, dy, dz, f.wx, f.wy, f.wz);
-    float rdz = dot3(dx, dy, dz, f.vx, f.vy, f.vz);
-    float xx = rox * rdx, yy = roy * rdy, zz = roz * rdz;
-    float n = (zz + yy) + xx;
-    float sx = rox * rox, sy = roy * roy, sz = roz * roz;
-    float m = (sz + sy) + sx;
-    float rd_dxz = rdx * rdx + rdz * rdz;
-    float ro_rd_dxz = xx + zz;
-    float ro_dxz = sx + sz;
-    float k = (m + f.R2) - f.r2;
-    float four_n = 4.0f * n;
-    float A = four_n;
-    float B = (2.0f * k + four_n * n) - f.fourR2 * rd_dxz;
-    float C = four_n * k - f.eightR2 * ro_rd_dxz;
-    float D = k * k - f.fourR2 * ro_dxz;
-    float t;
-    bool found = quartic_nearest<DEBUG>(A, B, C, D, t, cnt);
-    if (found && polish) t = newton_polish(A, B, C, D, t);
-    t_out = t;
-    return found;
-}
-
-// ------------------------------------------------------------------ trace (fragment_shader.glsl:379-435)
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// Centre of object `id` from the pair-interleaved bound records.
-DEV void object_centre(const float *lds, int id, float &cx, float &cy, float &cz)
-{
-    const float *p = lds + 8 * (id >> 1) + (id & 1);
-    cx = p[0]; cy = p[2]; cz = p[4];
-}
-
-// Exact test of one object whose bounding test did not reject it (:405-425).
-template <bool DEBUG>
-DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int i, float a,
-                        float ocx, float ocy, float ocz, float b, float c, float disc,
-                        float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
-{
-    CNT(EV_BOUND_TBOUND);
-    WCNT(WP_CAND); LCNT(WP_CAND_LANES);
-    // t_bound > closest.t can only hold once something has been hit: while closest.t is
-    // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
-    if (bt < 1e30f) {
-        WCNT(WP_TBOUND);
-        float t_bound = -b - rt_sqrt(disc);
-        if (t_bound > bt) return;
-    }
-    int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
-    float t; bool hit;
-    if (kd < 0) {
-        // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
-        CNT(EV_SPHERE_CALL);
-        WCNT(WP_SPHERE); LCNT(WP_SPHERE_LANES);
-        float b2 = 2.0f * b;
-        float ds = b2 * b2 - (4.0f * a) * c;
-        hit = false; t = 0.0f;
-        if (!(ds < 0.0f)) {
-            float sq = rt_sqrt(ds);
-            float two_a = 2.0f * a;
-            CNT(EV_SPHERE_ROOT);
-            t = rt_div(-b2 - sq, two_a);
-            if (t < 0.0f) { CNT(EV_SPHERE_ROOT); WCNT(WP_SPHERE_ROOT2); t = rt_div(-b2 + sq, two_a); }
-            hit = t > 0.001f;
-            if (hit) CNT(EV_SPHERE_HIT);
-        }
-    } else {
-        WCNT(WP_TORUS); LCNT(WP_TORUS_LANES);
-        TorusFrame f = load_torus(lds, L.off_torus, kd);
-        hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
-        if (hit) CNT(EV_TORUS_HIT);
-    }
-    if (hit && t < bt) { bt = t; bid = i; }
-}
-
-// intersect_plane (:107-123): y = -1, two-sided; tested after all objects (:428-433).
-template <bool DEBUG>
-DEV void offer_plane(float oy, float dy, int n, float &bt, int &bid, const Counters<DEBUG> &cnt)
-{
-    CNT(EV_PLANE_CALL);
-    bool ok = __builtin_fabsf(dy) > 0.0001f;
-    if (ok) {
-        CNT(EV_PLANE_T);
-        WCNT(WP_PLANE_DIV);
-        float t = rt_div(-1.0f - oy, dy);
-        if (t > 0.001f) {
-            CNT(EV_PLANE_HIT);
-            if (t < bt) { bt = t; bid = n; }
-        }
-    }
-}
-
-// Closest hit as (t, id): id -1 none, 0..n-1 scene object, n ground plane.
-// The bounding test (:399-402) runs on two objects per instruction with packed FP32 math
-// (v_pk_add/v_pk_mul: each half is an ordinary correctly rounded binary32 operation, so
-// the values are those of the scalar form); object order, and with it the tie rule "first
-// index wins" (:423), is kept by resolving the pair's candidates in index order.
-template <bool DEBUG>
-DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
-                       float ox, float oy, float oz, float dx, float dy, float dz,
-                       float &best_t, int &best_id, const Counters<DEBUG> &cnt)
-{
-    CNT(EV_TRACE);
-    float bt = 1e30f;
-    int bid = -1;
-    const float4 *pairs = reinterpret_cast<const float4 *>(lds);
-    const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
-    const int n = L.n;
-    const int npairs = (n + 1) >> 1;
-    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
-    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
-    float4 A = make_float4(0, 0, 0, 0), B = A;
-    if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
-    for (int j = 0; j < npairs; ++j) {
-        WCNT(WP_PAIR);
-        v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
-        v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-        v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-        v2f c = oc2 - br2;
-        // the record is consumed: request the next pair's (LDS broadcast read) into the same
-        // registers; its latency is covered by the rest of this iteration
-        const int jn = (j + 1 < npairs) ? j + 1 : j;
-        A = pairs[2 * jn]; B = pairs[2 * jn + 1];
-        v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
-        v2f disc = b * b - c;
-        if (DEBUG) {
-            const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
-            if (kind[2 * j] >= 0) CNT(EV_BOUND_TORUS_RADIUS);
-            if (2 * j + 1 < n && kind[2 * j + 1] >= 0) CNT(EV_BOUND_TORUS_RADIUS);
-            if (disc.x < 0.0f) CNT(EV_BOUND_CULL_DISC);
-            if (2 * j + 1 < n && disc.y < 0.0f) CNT(EV_BOUND_CULL_DISC);
-        }
-        if (!(disc.x < 0.0f))
-            test_candidate<DEBUG>(lds, L, polish, 2 * j, a, ocx.x, ocy.x, ocz.x, b.x, c.x, disc.x, dx, dy, dz, bt, bid, cnt);
-        // an odd object count is padded with a record whose radius^2 is -inf: disc = -inf
-        if (!(disc.y < 0.0f))
-            test_candidate<DEBUG>(lds, L, polish, 2 * j + 1, a, ocx.y, ocy.y, ocz.y, b.y, c.y, disc.y, dx, dy, dz, bt, bid, cnt);
-    }
-    offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
-    best_t = bt; best_id = bid;
-}
-
-// ------------------------------------------------------------------ trace through the sphere hierarchy
-//
-// The reference's loop (:386-426) only ever acts on objects whose bounding test passes
-// (disc >= 0); for those, what it does depends on the order (the t_bound > closest.t skip and
-// "first index wins").  trace_hierarchy therefore (1) finds exactly the set of objects whose
-// bounding test passes, by walking two levels of enclosing spheres and running the reference's
-// own bounding arithmetic on the members of the leaf nodes it reaches, and (2) replays the
-// reference's loop body over that set in ascending object index.  Step 2 is the reference
-// algorithm with the iterations it would have culled left out, so the result is the same
-// (t, id) for every ray, whatever the enclosing spheres look like -- provided step 1 never
-// drops an object that passes.  A node (centre g, radius R) is kept when
-//     disc_node + slack >= 0     (or the comparison is unordered: NaN/inf keep everything)
-// where disc_node is the bounding discriminant of the sphere (g, R + grow), with
-//     reach = |o - scene centre| + scene radius  (>= |oc| + radius for every object and node),
-//     grow  = sf * reach,  sf^2 = 2.5e-6 + 1.1 |dot(d,d) - 1|,
-//     slack = sf^2 (reach^2 + (reach + grow)^2).
-// Why that is enough: a member whose binary32 disc is >= 0 has its centre within
-// br + sqrt(E) of the ray's line, where E <= (17u + |dot(d,d) - 1|) |oc|^2 + 2u br^2
-// (u = 2^-24) bounds the rounding of the member test plus the direction's deviation from unit
-// length, so sqrt(E) <= grow; the member's sphere lies inside the node's, so the line passes
-// within R + grow of g, i.e. the exact node discriminant is >= 0, and the binary32 one
-// differs from it by less than sf^2 (|oc_node|^2 + (R + grow)^2) <= slack.
-//
-// The candidates are queued per ray in LDS as 16-bit object indices; a ray that collects
-// more than RT_QUEUE of them walks all objects in step 2 instead (same result, slower).
-DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v2f DZ, float grow, float slack,
-                   bool &keep0, bool &keep1)
-{
-    v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, R = {B.z, B.w};
-    v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-    v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-    v2f G = {grow, grow}, S = {slack, slack};
-    v2f Re = R + G;
-    v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
-    v2f disc = b * b - (oc2 - Re * Re);
-    v2f s = disc + S;
-    keep0 = !(s.x < 0.0f);
-    keep1 = !(s.y < 0.0f);
-}
-
-template <bool DEBUG>
-DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L, int polish, unsigned short *queue,
-                         float ox, float oy, float oz, float dx, float dy, float dz,
-                         float &best_t, int &best_id, const Counters<DEBUG> &cnt)
-{
-    const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
-    const int n = L.n, n1 = L.n1, n2 = L.n2;
-    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
-    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
-    // growth and slack of the node test, once per ray: every object and node lies inside the
-    // scene sphere (L.hc, L.hR), so |oc| + R <= reach = |o - hc| + hR for all of them
-    float sf2 = 2.5e-6f + 1.1f * __builtin_fabsf(a - 1.0f);
-    const float sf = __builtin_amdgcn_sqrtf(sf2) * 1.02f;
-    const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
-    const float reach = (__builtin_amdgcn_sqrtf((qz * qz + qy * qy) + qx * qx) + L.hR) * 1.0001f;
-    const float grow = sf * reach;
-    const float slack = (sf2 * 1.05f) * (reach * reach + (reach + grow) * (reach + grow)) + 1e-30f;
-    // hl = the hierarchy sections in LDS, starting at the top nodes
-    const float4 *top = reinterpret_cast<const float4 *>(hl);
-    const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
-    const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
-    const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
-
-    // ---- step 1: collect the objects whose bounding test passes.
-    // The top nodes are tested by all lanes together; below them every lane walks its own
-    // list of kept nodes (bit masks), so a wave of incoherent rays pays for the longest list
-    // of any lane, not for the union of all lists.
-    int count = 0;
-    unsigned int top_mask = 0;
-    for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
-        bool k0, k1;
-        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
-        top_mask |= (k0 ? 1u : 0u) << (2 * j);
-        top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
-    }
-    unsigned long long leaf_lo = 0, leaf_hi = 0;        // kept leaf nodes 0..63 / 64..127
-    const int last_leaf_pair = (n1 - 1) >> 1;
-    while (top_mask) {
-        const int tn = __builtin_ctz(top_mask);
-        top_mask &= top_mask - 1;
-        const int first = tn * RT_FAN;                       // first leaf node of this top node
-        const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
-        unsigned int bits = 0;
-#pragma unroll
-        for (int kk = 0; kk < RT_FAN / 2; ++kk) {
-            int lp = (first >> 1) + kk;
-            lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
-            bool k0, k1;
-            node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
-            bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
-            bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
-        }
-        const unsigned long long placed = (unsigned long long)bits << (first & 63);
-        if (first < 64) leaf_lo |= placed; else leaf_hi |= placed;
-    }
-    while (leaf_lo | leaf_hi) {
-        int leaf;
-        if (leaf_lo) { leaf = __builtin_ctzll(leaf_lo); leaf_lo &= leaf_lo - 1; }
-        else { leaf = 64 + __builtin_ctzll(leaf_hi); leaf_hi &= leaf_hi - 1; }
-#pragma unroll
-        for (int m = 0; m < RT_LEAF / 2; ++m) {
-            const int mp = leaf * (RT_LEAF / 2) + m;
-            const float4 A = memb[2 * mp], B = memb[2 * mp + 1];
-            // the reference's bounding test (:399-402), operation for operation
-            v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
-            v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-            v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-            v2f c = oc2 - br2;
-            v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
-            v2f disc = b * b - c;
-            if (!(disc.x < 0.0f)) {
-                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp];
-                count++;
-            }
-            if (!(disc.y < 0.0f)) {
-                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp + 1];
-                count++;
-            }
-        }
-    }
-
-    // ---- step 2: the reference's loop body over the candidates in ascending index
-    CNT(EV_TRACE);
-    float bt = 1e30f;
-    int bid = -1;
-    const bool walk_all = count > RT_QUEUE;
-    int last = -1;
-    for (;;) {
-        int i;
-        if (!walk_all) {
-            int mnext = 0x7fffffff;
-            for (int q = 0; q < count; ++q) {
-                int v = queue[q * 256];
-                mnext = (v > last && v < mnext) ? v : mnext;
-            }
-            if (mnext == 0x7fffffff) break;
-            i = mnext;
-        } else {
-            i = last + 1;
-            if (i >= n) break;
-        }
-        last = i;
-        const float *rec = sc + 8 * (i >> 1) + (i & 1);
-        float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
-        float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-        float c = oc2 - rec[6];
-        float b = (ocz * dz + ocy * dy) + ocx * dx;
-        float disc = b * b - c;
-        if (disc < 0.0f) continue;
-        test_candidate<DEBUG>(sc, L, polish, i, a, ocx, ocy, ocz, b, c, disc, dx, dy, dz, bt, bid, cnt);
-    }
-    offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
-    best_t = bt; best_id = bid;
-}
+namespace RT_NS {
 
 // ------------------------------------------------------------------ pending-ray slots
 template <int CAP> struct Pending {
