@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     e0.record(stream)
     run(args.steps)
+    host_issue_s = time.perf_counter() - t0          # host time to enqueue the steps (before any sync)
     e1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -200,6 +201,7 @@ def main():
         }
         if kernel_only_ms is not None:
             result["kernel_only_ms_per_step"] = kernel_only_ms      # value above includes gather + assemble
+            result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
     if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
