@@ -116,6 +116,12 @@ def main():
     scene, cam = scene(), cam()
     rt355.set_scene(scene)
     flags = rt355.api.FLAG_FAST_MATH if args.fast_math else 0
+    # between GPUs the parts travel as packed RGB8 (alpha is the constant 255 and is put back by
+    # the assemble kernel): a quarter less through the xGMI links, which bound this cheap frame
+    # (RT_BENCH_RGBA_TRANSPORT=1 sends RGBA8 instead, for an A/B)
+    tch = 4 if (not use_dist or os.environ.get("RT_BENCH_RGBA_TRANSPORT") == "1") else 3
+    if tch == 3:
+        flags |= rt355.api.FLAG_OUT_RGB8
     params = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
                                    shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags, part=rank, nparts=world)
     # a real (non-null) stream: the kernels, the RCCL hand-off and the timing events all go
@@ -131,15 +137,23 @@ def main():
         if rc != 0:
             raise RuntimeError(lib.rt_last_error().decode())
 
+    # Split frames alternate between two streams, so that the last waves of one frame's part
+    # overlap the first waves of the next (RT_BENCH_ONE_STREAM=1 keeps them on one, for an A/B)
+    streams = None
+    if use_dist and os.environ.get("RT_BENCH_ONE_STREAM") != "1":
+        streams = [stream, torch.cuda.Stream(device=dev)]
+
+    def cur_stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if streams else sptr
+
     def render_part(part, nparts, out):
-        check(lib.rt_render_device(pptr, out.data_ptr(), out.numel(), sptr, 0))
+        check(lib.rt_render_device(pptr, out.data_ptr(), out.numel(), cur_stream(), 0))
 
     def assemble(gathered, image):
-        check(lib.rt_assemble_device(gathered.data_ptr(), image.data_ptr(), W, H, world, 4, sptr))
+        check(lib.rt_assemble_device(gathered.data_ptr(), image.data_ptr(), W, H, world, tch, cur_stream()))
 
-    pipe = tiling.BandPipeline(H, W, 4, torch.uint8, dev, dist if use_dist else None, render_part, assemble,
-                               always_gather=force_gather)
-    image = pipe.image
+    pipe = tiling.BandPipeline(H, W, tch, torch.uint8, dev, dist if use_dist else None, render_part, assemble,
+                               always_gather=force_gather, image_channels=4, streams=streams)
 
     def run(steps):
         for _ in range(steps):
@@ -182,6 +196,22 @@ def main():
         t = torch.tensor([k0.elapsed_time(k1) / k_steps], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kernel_only_ms = float(t.item())
+        kernel_only_2s_ms = None
+        if streams:
+            # the same launches alternating between the two streams
+            barrier()
+            streams[1].wait_stream(streams[0])
+            k0.record(stream)
+            for i in range(k_steps):
+                torch.cuda.set_stream(streams[i % 2])
+                render_part(rank, world, pipe.mine[i % 2])
+            torch.cuda.set_stream(stream)
+            stream.wait_stream(streams[1])
+            k1.record(stream)
+            torch.cuda.synchronize()
+            t = torch.tensor([k0.elapsed_time(k1) / k_steps], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            kernel_only_2s_ms = float(t.item())
 
     result = None
     if rank == 0:
@@ -197,10 +227,13 @@ def main():
                     else "synthetic (seeded stress scene of the benchmark list)",
             "config": {"workload": wl["text"] % wl,
                        "numerics": "fast" if args.fast_math else "strict (bit-identical to the reference shader)",
-                       "tiling": "%d x interleaved 16-row bands, RCCL gather to GPU 0" % world if world > 1 else "single GPU"},
+                       "tiling": "%d x interleaved 16-row bands, RCCL gather to GPU 0 (parts travel as %s)" % (world, "RGB8" if tch == 3 else "RGBA8")
+                                 if use_dist else "single GPU"},
         }
         if kernel_only_ms is not None:
             result["kernel_only_ms_per_step"] = kernel_only_ms      # value above includes gather + assemble
+            if kernel_only_2s_ms is not None:
+                result["kernel_only_two_streams_ms_per_step"] = kernel_only_2s_ms
             result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
@@ -213,6 +246,7 @@ def main():
         flops = rt355.frame_flops(ev)
         kernel_ms = stream_ms / args.steps          # back-to-back launches of the one kernel on this stream
         tim = rt355.api.RtTiming()
+        image = pipe.image
         check(lib.rt_render_device(ctypes.addressof(full), image.data_ptr(), image.numel(), sptr, 1))
         torch.cuda.synchronize()
         check(lib.rt_get_timing(ctypes.addressof(tim)))
@@ -255,7 +289,7 @@ def main():
             import hashlib
             golden = json.load(open(os.path.join(ROOT, "tests", "golden", "default_4k_d8s3.json")))
             if not args.fast_math and args.stack_size == STACK_SIZE and headline:
-                got = hashlib.sha256(image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
+                got = hashlib.sha256(pipe.image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
                 result["gathered_frame_sha_ok"] = got == golden["sha256_rgba8"]
         print(json.dumps(result))
     if use_dist:

@@ -60,9 +60,12 @@ enum {
     RT_FLAG_NEWTON_POLISH = 1u << 1,  /* two Newton steps on the selected torus root               */
     RT_FLAG_BOTTOM_UP     = 1u << 2,  /* rows in GL order (row 0 = bottom); default row 0 = top     */
     RT_FLAG_OUT_F32       = 1u << 3,  /* write float RGBA (unclamped, alpha 1) instead of RGBA8     */
-    RT_FLAG_NO_ACCEL      = 1u << 4   /* always run the plain per-object loop of the reference, also
-                                         on large scenes (the uniform-grid traversal used there
+    RT_FLAG_NO_ACCEL      = 1u << 4,  /* always run the plain per-object loop of the reference, also
+                                         on large scenes (the sphere-hierarchy traversal used there
                                          returns the same hits; this flag exists to verify that)   */
+    RT_FLAG_OUT_RGB8      = 1u << 5   /* write packed RGB8, 3 bytes per pixel (the reference's alpha
+                                         is the constant 1.0, fragment_shader.glsl:674): a quarter
+                                         less to move between GPUs and to the host; not with OUT_F32 */
 };
 
 /* The uniforms of fragment_shader.glsl:12-15 as main.py:277-280 sets them, plus the
@@ -119,7 +122,10 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
 int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_t out_bytes);
 
 /* After a split render: `d_gathered` holds the nparts packed buffers back to back in part
- * order (what a gather to GPU 0 delivers); writes the assembled frame to `d_image`.       */
+ * order (what a gather to GPU 0 delivers), each padded to the size of part 0; writes the
+ * assembled frame to `d_image`.  bytes_per_pixel is that of the gathered buffers: 4 (RGBA8)
+ * and 16 (float RGBA) give an image of the same format, 3 (RGB8) gives an RGBA8 image with
+ * alpha 255.                                                                              */
 int rt_assemble_device(const void *d_gathered, void *d_image, int width, int height,
                        int nparts, int bytes_per_pixel, void *stream);
 

@@ -27,6 +27,7 @@ FLAG_NEWTON_POLISH = 1 << 1
 FLAG_BOTTOM_UP = 1 << 2
 FLAG_OUT_F32 = 1 << 3
 FLAG_NO_ACCEL = 1 << 4
+FLAG_OUT_RGB8 = 1 << 5
 
 
 class RtError(RuntimeError):
@@ -171,10 +172,10 @@ def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_g
     return p
 
 
-def _flags(fast_math, newton_polish, bottom_up, out_f32, no_accel=False):
+def _flags(fast_math, newton_polish, bottom_up, out_f32, no_accel=False, out_rgb8=False):
     return ((FLAG_FAST_MATH if fast_math else 0) | (FLAG_NEWTON_POLISH if newton_polish else 0) |
             (FLAG_BOTTOM_UP if bottom_up else 0) | (FLAG_OUT_F32 if out_f32 else 0) |
-            (FLAG_NO_ACCEL if no_accel else 0))
+            (FLAG_NO_ACCEL if no_accel else 0) | (FLAG_OUT_RGB8 if out_rgb8 else 0))
 
 
 def set_scene(scene):
@@ -183,23 +184,30 @@ def set_scene(scene):
     _check(L.rt_set_scene(ctypes.addressof(arr), len(scene)))
 
 
-def render_rgba(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
-                fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
-                no_accel=False):
-    """Render and return (rows, w, 4): uint8 RGBA as the reference's RGBA8 back buffer would
-    hold it (main.py:303), or float32 unclamped colour with out_f32.  Row 0 is the TOP row
-    unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands."""
+def _render_host(scene, camera, w, h, channels, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
+                 fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
+                 no_accel=False):
     L = _ensure_init()
     arr = pack_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
-                    spp_grid=spp_grid, flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel),
+                    spp_grid=spp_grid,
+                    flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel, out_rgb8=channels == 3),
                     part=part, nparts=nparts)
     nbytes = L.rt_output_bytes(ctypes.addressof(p))
-    bpp = 16 if out_f32 else 4
+    bpp = 16 if out_f32 else channels
     rows = nbytes // (bpp * int(w)) if w > 0 else 0
-    out = np.empty((rows, int(w), 4), dtype=np.float32 if out_f32 else np.uint8)
+    out = np.empty((rows, int(w), channels), dtype=np.float32 if out_f32 else np.uint8)
     _check(L.rt_render(ctypes.addressof(arr), len(scene), ctypes.addressof(p), out.ctypes.data, out.nbytes))
     return out
+
+
+def render_rgba(scene, camera, w, h, **opts):
+    """Render and return (rows, w, 4): uint8 RGBA as the reference's RGBA8 back buffer would
+    hold it (main.py:303), or float32 unclamped colour with out_f32.  Row 0 is the TOP row
+    unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands.
+    opts: max_depth, stack_size, shadow_hops, spp_grid, fast_math, newton_polish, bottom_up,
+    out_f32, part, nparts, no_accel."""
+    return _render_host(scene, camera, w, h, 4, **opts)
 
 
 def render(scene, camera, w, h, **opts) -> np.ndarray:
@@ -209,8 +217,13 @@ def render(scene, camera, w, h, **opts) -> np.ndarray:
     camera: Camera or dict(eye, yaw, pitch, focal_length[, light_pos]) (main.py:102-109, :278)
     opts  : max_depth=4, stack_size=3, shadow_hops=2 (the constants of fragment_shader.glsl:653,
             :547, :453), spp_grid=1, fast_math=False, newton_polish=False
+
+    The kernel writes packed RGB8 (the reference's alpha is the constant 1.0), so the read-back
+    is three bytes per pixel.
     """
-    return np.ascontiguousarray(render_rgba(scene, camera, w, h, **opts)[..., :3])
+    if opts.get("out_f32"):
+        raise RtError(-2, "render returns uint8 RGB; use render_rgba(out_f32=True) for float colour")
+    return _render_host(scene, camera, w, h, 3, **opts)
 
 
 def timing() -> dict:

@@ -97,6 +97,8 @@ int validate_params(const rt_params *p)
         return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d pending-ray slots per lane",
                     need, RT_MAX_PENDING);
     if (p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return fail(RT_E_ARG, "bad part/nparts");
+    if ((p->flags & RT_FLAG_OUT_F32) && (p->flags & RT_FLAG_OUT_RGB8))
+        return fail(RT_E_ARG, "RT_FLAG_OUT_F32 and RT_FLAG_OUT_RGB8 exclude each other");
     for (int i = 0; i < 16; ++i)
         if (!std::isfinite(p->cam_to_world[i])) return fail(RT_E_ARG, "camera matrix is not finite");
     if (!std::isfinite(p->focal_length)) return fail(RT_E_ARG, "focal length is not finite");
@@ -140,7 +142,7 @@ KParams make_kparams(const rt_params *p)
     k.work_counter = g.d_work;      // launches that use the queue are ordered on the GPU (workspace event)
     k.resident_workgroups = g.resident_workgroups;
     k.pend_ws = g.d_pend_ws;
-    k.out_f32 = (p->flags & RT_FLAG_OUT_F32) ? 1 : 0;
+    k.out_mode = (p->flags & RT_FLAG_OUT_F32) ? 1 : (p->flags & RT_FLAG_OUT_RGB8) ? 2 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
     // development aid: RT_WAVE_PROFILE=1 makes rt_count_events return the wave-level block
@@ -484,7 +486,7 @@ int rt_stage_scene_host(const rt_object *objs, int n, float *blob, size_t blob_d
 size_t rt_output_bytes(const rt_params *p)
 {
     if (!p || p->width <= 0 || p->height <= 0 || p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return 0;
-    size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : 4;
+    size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : (p->flags & RT_FLAG_OUT_RGB8) ? 3 : 4;
     return (size_t)part_rows(p) * (size_t)p->width * bpp;
 }
 
@@ -631,19 +633,65 @@ __global__ void assemble_kernel(const uint32_t *__restrict__ gathered, uint32_t 
     image[(size_t)row * width_dw + x] = gathered[part * part_stride_dw + src_row * width_dw + x];
 }
 
+// The same for packed RGB8 parts: expands to RGBA8 (alpha 255) on the way.  One thread per
+// pixel; with QUADS one thread per four pixels (3 dwords in, 4 out; needs width % 4 == 0).
+__global__ void assemble_rgb8_kernel(const uint8_t *__restrict__ gathered, uint32_t *__restrict__ image, int width,
+                                     int height, int nparts, size_t part_stride_bytes, int QUADS)
+{
+    int x = (blockIdx.x * blockDim.x + threadIdx.x) * (QUADS ? 4 : 1);
+    int row = blockIdx.y;
+    if (x >= width || row >= height) return;
+    int band = row / RT_BAND_ROWS;
+    int part = band % nparts;
+    int local_band = band / nparts;
+    size_t src_row = (size_t)local_band * RT_BAND_ROWS + (row - band * RT_BAND_ROWS);
+    const uint8_t *src = gathered + part * part_stride_bytes + (src_row * width + x) * 3;
+    uint32_t *dst = image + (size_t)row * width + x;
+    if (QUADS) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t a = s4[0], b = s4[1], c = s4[2];
+        uint4 v;
+        v.x = (a & 0x00ffffffu) | 0xff000000u;
+        v.y = (a >> 24) | ((b & 0x0000ffffu) << 8) | 0xff000000u;
+        v.z = (b >> 16) | ((c & 0x000000ffu) << 16) | 0xff000000u;
+        v.w = (c >> 8) | 0xff000000u;
+        *reinterpret_cast<uint4 *>(dst) = v;
+    } else {
+        *dst = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | 0xff000000u;
+    }
+}
+
 int rt_assemble_device(const void *d_gathered, void *d_image, int width, int height, int nparts,
                        int bytes_per_pixel, void *stream)
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
-    if (!d_gathered || !d_image || width <= 0 || height <= 0 || nparts < 1 || (bytes_per_pixel != 4 && bytes_per_pixel != 16))
+    if (!d_gathered || !d_image || width <= 0 || height <= 0 || nparts < 1 ||
+        (bytes_per_pixel != 3 && bytes_per_pixel != 4 && bytes_per_pixel != 16))
         return fail(RT_E_ARG, "bad assemble arguments");
     // every part's buffer is padded to the size of part 0 (the largest), as a gather of
     // equal-sized chunks delivers them
     rt_params p0{};
     p0.width = width; p0.height = height; p0.part = 0; p0.nparts = nparts;
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
+    if (bytes_per_pixel == 3) {
+        size_t stride = (size_t)part_rows(&p0) * width * 3;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(d_gathered);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(d_image);
+        // dword reads of the source and 16-byte writes of the image need aligned rows
+        const bool quads = width % 4 == 0 && stride % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 4 == 0 &&
+                           reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+        if (quads) {
+            dim3 grid((width / 4 + 255) / 256, height);
+            hipLaunchKernelGGL(assemble_rgb8_kernel, grid, dim3(256), 0, s, src, dst, width, height, nparts, stride, 1);
+        } else {
+            dim3 grid((width + 255) / 256, height);
+            hipLaunchKernelGGL(assemble_rgb8_kernel, grid, dim3(256), 0, s, src, dst, width, height, nparts, stride, 0);
+        }
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    }
     size_t stride_dw = (size_t)part_rows(&p0) * width * (bytes_per_pixel / 4);
     int width_dw = width * (bytes_per_pixel / 4);
-    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
     dim3 grid((width_dw + 255) / 256, height);
     hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint32_t *>(d_gathered),
                        reinterpret_cast<uint32_t *>(d_image), width_dw, height, nparts, stride_dw);

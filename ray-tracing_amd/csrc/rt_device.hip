@@ -125,11 +125,22 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     int px, packed_row, gy;     // pixel column, row inside this part's buffer, GL row (0 = bottom)
     bool active;
     if (!REFILL) {
-        px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-        const int band = kp.part + blockIdx.y * kp.nparts;
+        // Dispatch order of the 16x16 tiles (the hardware walks blockIdx.x fastest): down the
+        // columns of the image, the columns taken from the centre outwards.  Rows of an image are
+        // alike (all sky, all ground) and a column crosses everything, so in raster order the
+        // deep tiles of the object rows run together and the last ones finish alone; down the
+        // columns every stretch of the dispatch sequence holds the frame's mix of cheap and deep
+        // tiles, and the deep ones (a centred subject) are under way early.  The image does not
+        // depend on the order.
+        const int tiles_x16 = (int)gridDim.y;
+        const int k = (int)blockIdx.y, mid = tiles_x16 >> 1;
+        const int bx = (k & 1) ? (mid - 1 - (k >> 1)) : (mid + (k >> 1));
+        const int by = (int)blockIdx.x;
+        px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+        const int band = kp.part + by * kp.nparts;
         const int in_band = (wave >> 1) * 8 + (lane >> 3);
         const int row = band * 16 + in_band;             // output row
-        packed_row = blockIdx.y * 16 + in_band;
+        packed_row = by * 16 + in_band;
         active = px < kp.w && row < kp.h;
         gy = kp.bottom_up ? row : (kp.h - 1 - row);
     } else {
@@ -206,15 +217,20 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         float cr = fr, cg = fg, cb = fb;
         if (MULTI) { cr = accr * inv_spp; cg = accg * inv_spp; cb = accb * inv_spp; }
         size_t o = (size_t)packed_row * kp.w + px;
-        if (kp.out_f32) {
+        if (kp.out_mode == 1) {
             reinterpret_cast<float4 *>(out)[o] = make_float4(cr, cg, cb, 1.0f);
         } else {
             auto u8 = [](float c) -> uint32_t {
                 float s = !(c > 0.0f) ? 0.0f : (c >= 1.0f ? 1.0f : c);
                 return (uint32_t)__builtin_rintf(s * 255.0f);
             };
-            uint32_t v = u8(cr) | (u8(cg) << 8) | (u8(cb) << 16) | 0xff000000u;
-            reinterpret_cast<uint32_t *>(out)[o] = v;
+            const uint32_t r8 = u8(cr), g8 = u8(cg), b8 = u8(cb);
+            if (kp.out_mode == 2) {
+                uint8_t *b = reinterpret_cast<uint8_t *>(out) + o * 3;
+                b[0] = (uint8_t)r8; b[1] = (uint8_t)g8; b[2] = (uint8_t)b8;
+            } else {
+                reinterpret_cast<uint32_t *>(out)[o] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            }
         }
     };
 
@@ -633,7 +649,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     int bands = (kp.h + 15) / 16;
     int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;
     if (my_bands <= 0 || kp.w <= 0) return 0;
-    dim3 grid((kp.w + 15) / 16, my_bands);
+    dim3 grid(my_bands, (kp.w + 15) / 16);       // x: band of this part, y: column slot (see the kernel)
     if (REFILL) {
         // persistent waves: no more workgroups than the queue has work for or the GPU can hold
         if (!kp.work_counter) return (int)hipErrorInvalidValue;

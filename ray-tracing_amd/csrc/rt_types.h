@@ -82,7 +82,7 @@ struct KParams {
     int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
     int whole_tiles;              // persistent waves take whole 8x8 tiles only (no per-lane refill)
     float *pend_ws;               // pending-ray workspace: resident_workgroups x RT_PEND_MAX x 11 x 256 floats
-    int out_f32;            // 0: RGBA8, 1: float4
+    int out_mode;           // 0: RGBA8, 1: float4, 2: RGB8 (3 bytes per pixel, packed)
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
     int wave_profile;       // debug flavour only: count executed code blocks per wave instead of events

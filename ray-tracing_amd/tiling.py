@@ -75,13 +75,18 @@ class BandPipeline:
     the data path is the gather; there is no exchange during rendering.
 
     render_part(part, nparts, out)   fills the (padded_rows, w, c) tensor `out` with this
-                                     rank's packed bands (asynchronously on the current
-                                     stream when `out` lives on a GPU)
-    assemble(gathered, image)        rank 0 only: (nparts, padded_rows, w, c) -> (h, w, c)
+                                     rank's packed bands (asynchronously on the *current*
+                                     torch stream when `out` lives on a GPU)
+    assemble(gathered, image)        rank 0 only: (nparts, padded_rows, w, c) -> (h, w, ci)
+
+    `channels` is what travels between ranks, `image_channels` (default: the same) what the
+    assembled frame holds: packed RGB8 parts (3) assembled into an RGBA8 frame (4) move a
+    quarter less over the links, which is what bounds a cheap frame.  A world of one renders
+    straight into the frame, so render_part then receives an image_channels tensor.
     """
 
     def __init__(self, height, width, channels, dtype, device, dist, render_part, assemble,
-                 always_gather=False):
+                 always_gather=False, image_channels=None, streams=None):
         import torch
         self.torch, self.dist = torch, dist
         self.rank = dist.get_rank() if dist is not None else 0
@@ -91,9 +96,20 @@ class BandPipeline:
         # a world of one renders straight into the image unless the caller wants the gather
         # path exercised (tests)
         self.direct = self.world == 1 and not (always_gather and dist is not None)
+        # Two GPU streams, frame k on streams[k % 2]: the last waves of a part (a pixel's ray
+        # tree is one lane's sequential work, ~0.1 ms for the deepest pixels of the default
+        # scene, however small the part) then overlap the first waves of the next frame's part
+        # instead of leaving the GPU idle.  Everything that touches the buffers of frame k
+        # (render, hand-over to the gather, wait, assemble) is issued on streams[k % 2], so
+        # frame k+2 is ordered behind frame k's gather and assemble by stream order alone.
+        self.streams = list(streams) if streams else None
+        assert self.streams is None or len(self.streams) == 2
         rows = padded_part_rows(height, self.world)
         self.mine = [torch.zeros((rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
-        self.image = torch.empty((height, width, channels), dtype=dtype, device=device) if self.rank == 0 else None
+        nimg = 2 if (self.streams and not self.direct) else 1
+        self.images = ([torch.empty((height, width, image_channels or channels), dtype=dtype, device=device)
+                        for _ in range(nimg)] if self.rank == 0 else None)
+        self.last_image = 0
         if self.rank == 0 and not self.direct:
             # the gather delivers straight into the slices of one contiguous buffer per frame in flight
             self.gathered = [torch.empty((self.world, rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
@@ -103,18 +119,30 @@ class BandPipeline:
         self.prev = None
         self.k = 0
 
+    @property
+    def image(self):
+        """The most recently completed frame (rank 0; None elsewhere)."""
+        return self.images[self.last_image] if self.images is not None else None
+
+    def _use_stream(self, k):
+        if self.streams is not None:
+            self.torch.cuda.set_stream(self.streams[k % 2])
+
     def _finish(self, k, work):
+        self._use_stream(k)
         work.wait()
         if self.rank == 0:
-            self.assemble(self.gathered[k % 2], self.image)
+            self.last_image = k % len(self.images)
+            self.assemble(self.gathered[k % 2], self.images[self.last_image])
 
     def step(self):
         k = self.k
         self.k += 1
         if self.direct:
-            self.render_part(0, 1, self.image)
+            self.render_part(0, 1, self.images[0])
             return
         buf = self.mine[k % 2]
+        self._use_stream(k)
         self.render_part(self.rank, self.world, buf)
         work = self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0, async_op=True)
         if self.prev is not None:
@@ -125,3 +153,7 @@ class BandPipeline:
         if self.prev is not None:
             self._finish(*self.prev)
             self.prev = None
+        if self.streams is not None:
+            # leave the caller on streams[0], ordered behind both
+            self.torch.cuda.set_stream(self.streams[0])
+            self.streams[0].wait_stream(self.streams[1])

@@ -40,7 +40,7 @@ def _worker(rank, world, port, w, h, q):
         src = 0
         for r0, r1 in tiling.part_row_ranges(h, part, nparts):
             gl = orc.render(scene, cam.matrix(), cam.focal_length, w, h, rows=(h - r1, h - r0), nthreads=2)["rgba8"]
-            a[src:src + (r1 - r0)] = gl[::-1]
+            a[src:src + (r1 - r0)] = gl[::-1][..., :a.shape[-1]]
             src += r1 - r0
         a[src:] = 0
 
@@ -56,8 +56,18 @@ def _worker(rank, world, port, w, h, q):
     for _ in range(3):
         pipe.step()
     pipe.flush()
+    # parts travelling as packed RGB (three channels), assembled into the RGBA frame
+    def assemble_rgb(gathered, image):
+        image[..., :3] = torch.from_numpy(tiling.assemble_numpy(gathered.numpy(), h, world))
+        image[..., 3] = 255
+
+    pipe3 = tiling.BandPipeline(h, w, 3, torch.uint8, "cpu", dist, render_part, assemble_rgb, image_channels=4)
+    for _ in range(2):
+        pipe3.step()
+    pipe3.flush()
     if rank == 0:
         assert np.array_equal(pipe.image.numpy(), single)
+        assert pipe3.image.shape == (h, w, 4) and np.array_equal(pipe3.image.numpy(), single)
         q.put(single)
     dist.barrier()
     dist.destroy_process_group()
