@@ -237,7 +237,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     const bool in_frame = active;       // fixed pixel per lane (without REFILL)
     // wave-uniform queue state (REFILL): the tile being handed out and its next unassigned pixel
     const int tiles_x8 = (kp.w + 7) >> 3;
-    const int ntiles = tiles_x8 * (kp.my_bands * 2);
+    const int tile_rows8 = kp.my_bands * 2;
+    const int ntiles = tiles_x8 * tile_rows8;
     int pool_tile = -1, pool_next = 64;
     int sq = (int)((blockIdx.x * 4u + (unsigned int)wave) % RT_SUBQUEUES), sq_tried = 0;
     bool exhausted = false;
@@ -264,7 +265,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 int new_tile = -1;
                 if (cross && !exhausted) {
                     // The queue is RT_SUBQUEUES interleaved sub-queues (sub-queue q holds the tiles
-                    // t = q mod RT_SUBQUEUES, in raster order), each behind its own counter: one
+                    // t = q mod RT_SUBQUEUES of the column-major sequence), each behind its own counter: one
                     // counter for the whole GPU sustains only ~1e8 operations per second, which
                     // bounded frames of cheap tiles; interleaving keeps all waves in the same
                     // region of the frame.  A wave drains the sub-queue it starts on, then moves
@@ -288,7 +289,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     const int tile = idx < 64 ? pool_tile : new_tile;
                     idx &= 63;
                     if (tile >= 0) {
-                        const int ty = tile / tiles_x8, tx = tile - ty * tiles_x8;
+                        // the queue walks the 8x8 tiles down the columns, the columns from the
+                        // centre outwards (as the one-pixel-per-lane kernels dispatch theirs)
+                        const int col = tile / tile_rows8, ty = tile - col * tile_rows8;
+                        const int mid8 = tiles_x8 >> 1;
+                        const int tx = (col & 1) ? (mid8 - 1 - (col >> 1)) : (mid8 + (col >> 1));
                         px = tx * 8 + (idx & 7);
                         packed_row = ty * 8 + (idx >> 3);
                         const int row = (kp.part + (packed_row >> 4) * kp.nparts) * 16 + (packed_row & 15);
