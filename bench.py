@@ -143,8 +143,10 @@ def main():
     if use_dist and os.environ.get("RT_BENCH_ONE_STREAM") != "1":
         streams = [stream, torch.cuda.Stream(device=dev)]
 
+    sptrs = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams] if streams else [sptr, sptr]
+
     def cur_stream():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if streams else sptr
+        return sptrs[pipe.cur]
 
     def render_part(part, nparts, out):
         check(lib.rt_render_device(pptr, out.data_ptr(), out.numel(), cur_stream(), 0))
@@ -203,9 +205,9 @@ def main():
             streams[1].wait_stream(streams[0])
             k0.record(stream)
             for i in range(k_steps):
-                torch.cuda.set_stream(streams[i % 2])
+                pipe._use_stream(i)
                 render_part(rank, world, pipe.mine[i % 2])
-            torch.cuda.set_stream(stream)
+            pipe._use_stream(0)
             stream.wait_stream(streams[1])
             k1.record(stream)
             torch.cuda.synchronize()

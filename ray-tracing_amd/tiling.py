@@ -118,6 +118,7 @@ class BandPipeline:
             self.chunks, self.gathered = None, None
         self.prev = None
         self.k = 0
+        self.cur = 0
 
     @property
     def image(self):
@@ -125,8 +126,11 @@ class BandPipeline:
         return self.images[self.last_image] if self.images is not None else None
 
     def _use_stream(self, k):
+        # self.cur: index into `streams` of the stream the callbacks are to launch on
+        # (torch.cuda.current_stream() costs ~9 us a call, a table lookup by the caller nothing)
+        self.cur = k % 2
         if self.streams is not None:
-            self.torch.cuda.set_stream(self.streams[k % 2])
+            self.torch.cuda.set_stream(self.streams[self.cur])
 
     def _finish(self, k, work):
         self._use_stream(k)
@@ -155,5 +159,6 @@ class BandPipeline:
             self.prev = None
         if self.streams is not None:
             # leave the caller on streams[0], ordered behind both
+            self.cur = 0
             self.torch.cuda.set_stream(self.streams[0])
             self.streams[0].wait_stream(self.streams[1])
