@@ -32,6 +32,10 @@
 //     started together): when lanes drift apart every code block of the loop runs on every
 //     iteration, which costs more than the idle lanes it saves -- except at depth 16 on large
 //     scenes, where per-lane pixel refill wins.
+//   * tiles are dispatched down the columns of the image, the columns from the centre outwards
+//     (grid of the one-pixel-per-lane kernels, tile queue of the persistent ones): a frame cannot
+//     finish before its deepest tile, rows of an image are alike and columns cross everything, so
+//     this order keeps cheap and deep tiles mixed on every SIMD and starts the deep ones early.
 // The arithmetic primitives are in rt_numerics.h, intersection and trace in rt_intersect.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
