@@ -125,3 +125,18 @@ def test_calls_fail_cleanly_without_init(rt):
     assert lib.rt_render_device(ctypes.addressof(p), out.ctypes.data, out.nbytes, None, 0) == -4
     assert b"rt_init" in lib.rt_last_error()
     assert lib.rt_output_bytes(ctypes.addressof(p)) == 8 * 8 * 4
+
+
+def test_output_bytes_per_format_and_part(rt):
+    """rt_output_bytes is host arithmetic: RGBA8 4, packed RGB8 3, float RGBA 16 bytes per pixel of
+    this part's bands (16 rows each, the last one ragged)."""
+    from importlib import import_module
+    tiling = import_module("ray-tracing_amd.tiling")
+    lib = rt.load_library()
+    cam = rt.default_camera()
+    for w, h, nparts in ((200, 150, 1), (37, 23, 2), (3840, 2160, 8), (1, 1, 3)):
+        for part in range(nparts):
+            rows = tiling.part_rows(h, part, nparts)
+            for flags, bpp in ((0, 4), (rt.api.FLAG_OUT_RGB8, 3), (rt.api.FLAG_OUT_F32, 16)):
+                p = rt.api.make_params(cam, w, h, part=part, nparts=nparts, flags=flags)
+                assert lib.rt_output_bytes(ctypes.addressof(p)) == rows * w * bpp
