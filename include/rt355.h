@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define RT_MAX_OBJECTS 1024   /* scene objects per frame                                 */
+#define RT_MAX_LIGHT_GRID 8   /* area light: at most 8 x 8 samples                        */
 #define RT_MAX_PENDING 16     /* min(stack_size, max_depth-1) must not exceed this       */
 #define RT_BAND_ROWS   16     /* rows per screen band when a frame is split over GPUs    */
 
@@ -85,6 +86,12 @@ typedef struct rt_params {
     int32_t part, nparts;       /* screen-space split: this call renders the bands b (RT_BAND_ROWS
                                    rows each, counted from the top of the image) with
                                    b % nparts == part, packed in band order; 0,1 = whole frame    */
+    int32_t light_grid;         /* G: the light is a horizontal square of edge light_size centred
+                                   on light_pos, sampled on a G x G grid (each sample with its own
+                                   shadow hops; the mean of the samples' diffuse + specular terms
+                                   joins the ambient term).  0 or 1 = the reference's point light
+                                   (main.py:278); at most RT_MAX_LIGHT_GRID                        */
+    float light_size;           /* edge of that square, >= 0                                      */
 } rt_params;
 
 typedef struct rt_timing {

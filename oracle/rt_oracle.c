@@ -34,6 +34,7 @@
 #endif
 
 #define ORC_MAX_STACK 64
+#define ORC_MAX_LIGHT_GRID 8
 
 /* Mirrors struct SceneObject, fragment_shader.glsl:41-56 (16 dwords, 64 bytes). */
 typedef struct {
@@ -56,6 +57,8 @@ typedef struct {
     int32_t stack_size;      /* fragment_shader.glsl:547 (3) */
     int32_t shadow_hops;     /* fragment_shader.glsl:453 (2) */
     int32_t spp_grid;        /* N: N x N stratified samples per pixel; 1 = reference */
+    int32_t light_grid;      /* G: G x G samples of a square area light; 0 or 1 = the reference's point light */
+    float light_size;        /* edge of that square (horizontal, centred on `light`) */
 } orc_params;
 
 /* ---- work counters (events), used for the algorithmic FLOP total ---- */
@@ -264,6 +267,9 @@ typedef struct {
     const orc_object *objs; int n;
     v3 light, cam_pos;
     int max_depth, stack_size, hops;
+    int light_grid;                         /* > 1: area light, see phong() */
+    float light_off[ORC_MAX_LIGHT_GRID];    /* offset of sample column/row i from the light's centre */
+    float inv_light;                        /* 1 / (light_grid * light_grid) */
 } scene_ctx;
 
 /* intersect_sphere, fragment_shader.glsl:74-103 */
@@ -486,11 +492,11 @@ static hit_t trace(const scene_ctx *sc, ray_t ray, counters *cnt)
 }
 
 /* calculate_light_attenuation, fragment_shader.glsl:439-483 */
-static v3 light_attenuation(const scene_ctx *sc, v3 point, counters *cnt)
+static v3 light_attenuation(const scene_ctx *sc, v3 light, v3 point, counters *cnt)
 {
     CNT(EV_ATTEN_FIXED);
     v3 filt = V(1.0f, 1.0f, 1.0f);
-    v3 to_l = vsub(sc->light, point);
+    v3 to_l = vsub(light, point);
     float d2 = dot3(to_l, to_l);
     float light_dist = sqrtf(d2);
     v3 L = vscale(to_l, rsq(d2));
@@ -516,14 +522,15 @@ static v3 light_attenuation(const scene_ctx *sc, v3 point, counters *cnt)
     return filt;
 }
 
-/* phong_lighting, fragment_shader.glsl:488-514 */
-static v3 phong(const scene_ctx *sc, const hit_t *h, counters *cnt)
+/* The light-dependent part of phong_lighting (fragment_shader.glsl:491-513) for one light
+ * position: (diffuse + specular) * attenuation.  Returns 0 when the light is fully blocked
+ * (the reference then returns the ambient term alone, :493-495). */
+static int phong_light_term(const scene_ctx *sc, v3 light, const hit_t *h, counters *cnt, v3 *term)
 {
-    v3 ambient = vscale(h->color, 0.05f);
-    v3 att = light_attenuation(sc, h->pos, cnt);
-    if ((att.z * att.z + att.y * att.y) == -(att.x * att.x)) { CNT(EV_PHONG_SHADOWED); return ambient; }
+    v3 att = light_attenuation(sc, light, h->pos, cnt);
+    if ((att.z * att.z + att.y * att.y) == -(att.x * att.x)) { CNT(EV_PHONG_SHADOWED); return 0; }
     CNT(EV_PHONG_FULL);
-    v3 to_l = vsub(sc->light, h->pos);
+    v3 to_l = vsub(light, h->pos);
     v3 L = vscale(to_l, rsq(dot3(to_l, to_l)));
     float nl_z = h->n.z * L.z, nl_y = h->n.y * L.y, nl_x = h->n.x * L.x;
     float ndl = (nl_z + nl_y) + nl_x;
@@ -538,7 +545,31 @@ static v3 phong(const scene_ctx *sc, const hit_t *h, counters *cnt)
     float sd = fmaxf(dot3(Vd, R), 0.0f);
     float spec = 0.5f * orc_pow(sd, 32.0f);
     v3 sum = V(diffuse.x + spec, diffuse.y + spec, diffuse.z + spec);
-    return V(ambient.x + sum.x * att.x, ambient.y + sum.y * att.y, ambient.z + sum.z * att.z);
+    *term = V(sum.x * att.x, sum.y * att.y, sum.z * att.z);
+    return 1;
+}
+
+/* phong_lighting, fragment_shader.glsl:488-514.  With light_grid G > 1 (not a reference
+ * feature) the point light becomes a horizontal square of edge light_size centred on it, sampled
+ * on a G x G grid: the light terms of the samples that are not fully blocked are added up in
+ * sample order (column index fastest) starting from 0, and the mean joins the ambient term:
+ * ambient + sum * (1 / G^2).  Ray paths, sky and ambient do not depend on the light, so this
+ * is, up to rounding, the mean of G^2 point-light frames before the clamp. */
+static v3 phong(const scene_ctx *sc, const hit_t *h, counters *cnt)
+{
+    v3 ambient = vscale(h->color, 0.05f);
+    v3 term;
+    if (sc->light_grid <= 1) {
+        if (!phong_light_term(sc, sc->light, h, cnt, &term)) return ambient;
+        return V(ambient.x + term.x, ambient.y + term.y, ambient.z + term.z);
+    }
+    v3 acc = V(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < sc->light_grid; ++j)
+        for (int i = 0; i < sc->light_grid; ++i) {
+            v3 light = V(sc->light.x + sc->light_off[i], sc->light.y, sc->light.z + sc->light_off[j]);
+            if (phong_light_term(sc, light, h, cnt, &term)) acc = V(acc.x + term.x, acc.y + term.y, acc.z + term.z);
+        }
+    return V(ambient.x + acc.x * sc->inv_light, ambient.y + acc.y * sc->inv_light, ambient.z + acc.z * sc->inv_light);
 }
 
 /* RayTraceIterative, fragment_shader.glsl:544-646 (with calculate_fresnel :524-534 inline).
@@ -650,12 +681,17 @@ static ray_t primary_ray(const orc_params *p, float fx, float fy)
     return r;
 }
 
+/* Offset of sample i on an N-grid from the centre, in units of the grid's extent (sub-pixel
+ * position of a stratified sample; position on the area light). */
+static inline float sample_offset(int i, int N) { return (float)(((double)i + 0.5) / (double)N - 0.5); }
+
 static int check_args(const orc_object *objs, int n, const orc_params *p)
 {
     if (!objs || !p || n < 0) return -1;
     if (p->w <= 0 || p->h <= 0) return -2;
     if (p->stack_size < 1 || p->stack_size > ORC_MAX_STACK) return -3;
     if (p->max_depth < 1 || p->shadow_hops < 0 || p->spp_grid < 1) return -4;
+    if (p->light_grid < 0 || p->light_grid > ORC_MAX_LIGHT_GRID || !(p->light_size >= 0.0f)) return -6;
     for (int i = 0; i < n; ++i) if (objs[i].type != 1 && objs[i].type != 2) return -5;
     return 0;
 }
@@ -666,10 +702,12 @@ static void make_ctx(scene_ctx *sc, const orc_object *objs, int n, const orc_par
     sc->light = V(p->light[0], p->light[1], p->light[2]);
     sc->cam_pos = V(p->cam_to_world[3], p->cam_to_world[7], p->cam_to_world[11]);
     sc->max_depth = p->max_depth; sc->stack_size = p->stack_size; sc->hops = p->shadow_hops;
+    sc->light_grid = p->light_grid > 1 ? p->light_grid : 1;
+    for (int i = 0; i < ORC_MAX_LIGHT_GRID; ++i)
+        sc->light_off[i] = i < sc->light_grid ? sample_offset(i, sc->light_grid) * p->light_size : 0.0f;
+    sc->inv_light = 1.0f / (float)(sc->light_grid * sc->light_grid);
 }
 
-/* Sub-pixel offset of sample i on an N-grid, relative to the pixel centre. */
-static inline float sample_offset(int i, int N) { return (float)(((double)i + 0.5) / (double)N - 0.5); }
 
 /* Framebuffer write: clamp to [0,1], scale by 255, round to nearest even (RGBA8 UNORM). */
 static inline uint8_t to_unorm8(float c)

@@ -25,7 +25,8 @@ class OrcObject(ctypes.Structure):
 class OrcParams(ctypes.Structure):
     _fields_ = [("cam_to_world", ctypes.c_float * 16), ("focal", ctypes.c_float), ("light", ctypes.c_float * 3),
                 ("w", ctypes.c_int32), ("h", ctypes.c_int32), ("max_depth", ctypes.c_int32),
-                ("stack_size", ctypes.c_int32), ("shadow_hops", ctypes.c_int32), ("spp_grid", ctypes.c_int32)]
+                ("stack_size", ctypes.c_int32), ("shadow_hops", ctypes.c_int32), ("spp_grid", ctypes.c_int32),
+                ("light_grid", ctypes.c_int32), ("light_size", ctypes.c_float)]
 
 
 _lib = None
@@ -76,7 +77,7 @@ def pack_scene(scene):
 
 
 def make_params(cam_to_world, focal, w, h, light=(-2.0, 4.0, 1.0), max_depth=4, stack_size=3,
-                shadow_hops=2, spp_grid=1):
+                shadow_hops=2, spp_grid=1, light_grid=1, light_size=0.0):
     p = OrcParams()
     m = np.ascontiguousarray(cam_to_world, dtype=np.float32).ravel()
     p.cam_to_world[:] = m.tolist()
@@ -84,6 +85,7 @@ def make_params(cam_to_world, focal, w, h, light=(-2.0, 4.0, 1.0), max_depth=4, 
     p.light[:] = [float(v) for v in light]
     p.w, p.h = int(w), int(h)
     p.max_depth, p.stack_size, p.shadow_hops, p.spp_grid = int(max_depth), int(stack_size), int(shadow_hops), int(spp_grid)
+    p.light_grid, p.light_size = int(light_grid), float(light_size)
     return p
 
 
@@ -94,11 +96,12 @@ def event_table():
 
 
 def render(scene, cam_to_world, focal, w, h, *, light=(-2.0, 4.0, 1.0), max_depth=4, stack_size=3,
-           shadow_hops=2, spp_grid=1, want_f32=False, want_events=False, rows=None, nthreads=None):
+           shadow_hops=2, spp_grid=1, light_grid=1, light_size=0.0, want_f32=False, want_events=False, rows=None,
+           nthreads=None):
     """Returns dict(rgba8=(h,w,4) uint8 bottom-up [, f32=(h,w,4) float32][, events=uint64[EV_COUNT]])."""
     L = lib()
     objs = pack_scene(scene)
-    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, spp_grid)
+    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, spp_grid, light_grid, light_size)
     y0, y1 = (0, h) if rows is None else rows
     nrows = y1 - y0
     u8 = np.empty((nrows, w, 4), dtype=np.uint8)

@@ -49,7 +49,7 @@ class RtParams(ctypes.Structure):
                 ("light_pos", ctypes.c_float * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("max_depth", ctypes.c_int32), ("stack_size", ctypes.c_int32), ("shadow_hops", ctypes.c_int32),
                 ("spp_grid", ctypes.c_int32), ("flags", ctypes.c_uint32), ("part", ctypes.c_int32),
-                ("nparts", ctypes.c_int32)]
+                ("nparts", ctypes.c_int32), ("light_grid", ctypes.c_int32), ("light_size", ctypes.c_float)]
 
 
 class RtTiming(ctypes.Structure):
@@ -159,7 +159,7 @@ def pack_scene(scene):
 
 
 def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1, flags=0,
-                part=0, nparts=1) -> RtParams:
+                part=0, nparts=1, light_grid=1, light_size=0.0) -> RtParams:
     cam = Camera.coerce(camera)
     p = RtParams()
     p.cam_to_world[:] = cam.matrix().ravel().tolist()
@@ -169,6 +169,7 @@ def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_g
     p.max_depth, p.stack_size, p.shadow_hops, p.spp_grid = int(max_depth), int(stack_size), int(shadow_hops), int(spp_grid)
     p.flags = int(flags)
     p.part, p.nparts = int(part), int(nparts)
+    p.light_grid, p.light_size = int(light_grid), float(light_size)
     return p
 
 
@@ -186,13 +187,13 @@ def set_scene(scene):
 
 def _render_host(scene, camera, w, h, channels, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
                  fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
-                 no_accel=False):
+                 no_accel=False, light_grid=1, light_size=0.0):
     L = _ensure_init()
     arr = pack_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
                     spp_grid=spp_grid,
                     flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel, out_rgb8=channels == 3),
-                    part=part, nparts=nparts)
+                    part=part, nparts=nparts, light_grid=light_grid, light_size=light_size)
     nbytes = L.rt_output_bytes(ctypes.addressof(p))
     bpp = 16 if out_f32 else channels
     rows = nbytes // (bpp * int(w)) if w > 0 else 0
@@ -206,7 +207,8 @@ def render_rgba(scene, camera, w, h, **opts):
     hold it (main.py:303), or float32 unclamped colour with out_f32.  Row 0 is the TOP row
     unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands.
     opts: max_depth, stack_size, shadow_hops, spp_grid, fast_math, newton_polish, bottom_up,
-    out_f32, part, nparts, no_accel."""
+    out_f32, part, nparts, no_accel, light_grid, light_size (G x G samples of a square area light
+    of that edge; 1 = the reference's point light)."""
     return _render_host(scene, camera, w, h, 4, **opts)
 
 
@@ -240,12 +242,14 @@ def event_table():
     return [L.rt_event_name(i).decode() for i in range(n)], np.array([L.rt_event_flops(i) for i in range(n)], dtype=np.int64)
 
 
-def count_events(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1, fast_math=False):
+def count_events(scene, camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1, fast_math=False,
+                 light_grid=1, light_size=0.0):
     """Per-frame work counters (uint64 per event class) from the instrumented kernel flavour."""
     L = _ensure_init()
     set_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
-                    spp_grid=spp_grid, flags=_flags(fast_math, False, False, False))
+                    spp_grid=spp_grid, flags=_flags(fast_math, False, False, False), light_grid=light_grid,
+                    light_size=light_size)
     ev = np.zeros(L.rt_event_count(), dtype=np.uint64)
     _check(L.rt_count_events(ctypes.addressof(p), ev.ctypes.data))
     return ev

@@ -97,6 +97,9 @@ int validate_params(const rt_params *p)
         return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d pending-ray slots per lane",
                     need, RT_MAX_PENDING);
     if (p->nparts < 1 || p->part < 0 || p->part >= p->nparts) return fail(RT_E_ARG, "bad part/nparts");
+    if (p->light_grid < 0 || p->light_grid > RT_MAX_LIGHT_GRID)
+        return fail(RT_E_LIMIT, "light_grid must be 0..%d", RT_MAX_LIGHT_GRID);
+    if (!(p->light_size >= 0.0f) || !std::isfinite(p->light_size)) return fail(RT_E_ARG, "light_size must be finite and >= 0");
     if ((p->flags & RT_FLAG_OUT_F32) && (p->flags & RT_FLAG_OUT_RGB8))
         return fail(RT_E_ARG, "RT_FLAG_OUT_F32 and RT_FLAG_OUT_RGB8 exclude each other");
     for (int i = 0; i < 16; ++i)
@@ -142,6 +145,10 @@ KParams make_kparams(const rt_params *p)
     k.work_counter = g.d_work;      // launches that use the queue are ordered on the GPU (workspace event)
     k.resident_workgroups = g.resident_workgroups;
     k.pend_ws = g.d_pend_ws;
+    k.light_grid = p->light_grid > 1 ? p->light_grid : 1;
+    k.inv_light = 1.0f / (float)(k.light_grid * k.light_grid);
+    for (int i = 0; i < RT_MAX_LIGHT_GRID; ++i)
+        k.light_off[i] = i < k.light_grid ? (float)(((double)i + 0.5) / (double)k.light_grid - 0.5) * p->light_size : 0.0f;
     k.out_mode = (p->flags & RT_FLAG_OUT_F32) ? 1 : (p->flags & RT_FLAG_OUT_RGB8) ? 2 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;

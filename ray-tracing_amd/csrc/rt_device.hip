@@ -216,6 +216,27 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         CNT(EV_PIXEL_PATH);
         WCNT(WP_START);
     };
+    // Area light (MULTI kernels, kp.light_grid = G > 1; not a reference feature): the point light
+    // becomes a horizontal square sampled on a G x G grid.  Per shaded hit the samples are visited
+    // in order (column index fastest), each with its own shadow hops; the light terms of the
+    // samples that are not fully blocked are summed from 0 and their mean joins the ambient term.
+    int li = 0, lj = 0;                      // light sample column / row
+    float lsr = 0, lsg = 0, lsb = 0;         // sum of the light terms so far
+    const bool area_light = MULTI && kp.light_grid > 1;
+    // calculate_light_attenuation set-up (:443-450) towards the current light sample
+    auto setup_shadow = [&]() {
+        CNT(EV_ATTEN_FIXED);
+        float qx = kp.light[0], qz = kp.light[2];
+        if (area_light) { qx = qx + kp.light_off[li]; qz = qz + kp.light_off[lj]; }
+        float lx = qx - hx, ly = kp.light[1] - hy, lz = qz - hz;
+        float d2 = dot3(lx, ly, lz, lx, ly, lz);
+        light_dist = rt_sqrt(d2);
+        float rs = rt_rsq(d2);
+        dx = lx * rs; dy = ly * rs; dz = lz * rs;      // shadow direction L
+        stx = dx * 0.001f; sty = dy * 0.001f; stz = dz * 0.001f;
+        ox = hx + stx; oy = hy + sty; oz = hz + stz;
+        filr = filg = filb = 1.0f; travelled = 0.0f; hop = 0;
+    };
     // RGBA8 UNORM conversion of the framebuffer write (:674): clamp, *255, round to even
     auto write_pixel = [&]() {
         float cr = fr, cg = fg, cb = fb;
@@ -424,16 +445,10 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 local = (1.0f - m_refl) - m_transp;
                 pdx = dx; pdy = dy; pdz = dz;
                 if (local > 0.0f) {
-                    // phong_lighting -> calculate_light_attenuation set-up (:443-450)
-                    CNT(EV_LOCAL); CNT(EV_ATTEN_FIXED); WCNT(WP_LOCAL);
-                    float lx = kp.light[0] - hx, ly = kp.light[1] - hy, lz = kp.light[2] - hz;
-                    float d2 = dot3(lx, ly, lz, lx, ly, lz);
-                    light_dist = rt_sqrt(d2);
-                    float rs = rt_rsq(d2);
-                    dx = lx * rs; dy = ly * rs; dz = lz * rs;      // shadow direction L
-                    stx = dx * 0.001f; sty = dy * 0.001f; stz = dz * 0.001f;
-                    ox = hx + stx; oy = hy + sty; oz = hz + stz;
-                    filr = filg = filb = 1.0f; travelled = 0.0f; hop = 0;
+                    // phong_lighting -> calculate_light_attenuation
+                    CNT(EV_LOCAL); WCNT(WP_LOCAL);
+                    if (MULTI) { li = 0; lj = 0; lsr = lsg = lsb = 0.0f; }
+                    setup_shadow();
                     if (kp.hops > 0) state = ST_SHADOW;             // trace the first hop next
                     else spawn = true;                               // zero hops: unattenuated
                 } else {
@@ -481,7 +496,8 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 // phong_lighting (:488-514) with attenuation = fil*, light direction = d (still L)
                 float ambr = 0.05f * mr, ambg = 0.05f * mg, ambb = 0.05f * mb;
                 float lcr = ambr, lcg = ambg, lcb = ambb;
-                if ((filb * filb + filg * filg) != -(filr * filr)) {
+                // (diffuse + specular) * attenuation of the light sample the shadow hops were cast to
+                auto light_term = [&](float &tr, float &tg, float &tb) {
                     CNT(EV_PHONG_FULL);
                     WCNT(WP_PHONG); LCNT(WP_PHONG_LANES);
                     float Lx = dx, Ly = dy, Lz = dz;
@@ -494,16 +510,45 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     float rx = -Lx - two_dn * nx, ry = -Ly - two_dn * ny, rz = -Lz - two_dn * nz;
                     float sd = max0(dot3(vx, vy, vz, rx, ry, rz));
                     float spec = 0.5f * rt_pow(sd, 32.0f);
-                    lcr = ambr + (diff * mr + spec) * filr;
-                    lcg = ambg + (diff * mg + spec) * filg;
-                    lcb = ambb + (diff * mb + spec) * filb;
+                    tr = (diff * mr + spec) * filr;
+                    tg = (diff * mg + spec) * filg;
+                    tb = (diff * mb + spec) * filb;
+                };
+                if (!area_light) {
+                    if ((filb * filb + filg * filg) != -(filr * filr)) {
+                        float tr, tg, tb;
+                        light_term(tr, tg, tb);
+                        lcr = ambr + tr; lcg = ambg + tg; lcb = ambb + tb;
+                    } else {
+                        CNT(EV_PHONG_SHADOWED);
+                    }
                 } else {
-                    CNT(EV_PHONG_SHADOWED);
+                    // this light sample's term, then the next sample's shadow ray -- or, after the
+                    // last one, the mean (with zero hops all samples are handled right here)
+                    for (;;) {
+                        if ((filb * filb + filg * filg) != -(filr * filr)) {
+                            float tr, tg, tb;
+                            light_term(tr, tg, tb);
+                            lsr = lsr + tr; lsg = lsg + tg; lsb = lsb + tb;
+                        } else {
+                            CNT(EV_PHONG_SHADOWED);
+                        }
+                        li++;
+                        if (li == kp.light_grid) { li = 0; lj++; }
+                        if (lj == kp.light_grid) break;
+                        setup_shadow();
+                        if (kp.hops > 0) { state = ST_SHADOW; spawn = false; break; }
+                    }
+                    lcr = ambr + lsr * kp.inv_light; lcg = ambg + lsg * kp.inv_light; lcb = ambb + lsb * kp.inv_light;
                 }
-                fr = fr + (lcr * local) * thx;
-                fg = fg + (lcg * local) * thy;
-                fb = fb + (lcb * local) * thz;
+                if (spawn) {
+                    fr = fr + (lcr * local) * thx;
+                    fg = fg + (lcg * local) * thy;
+                    fb = fb + (lcb * local) * thz;
+                }
             }
+        }
+        if (spawn) {
             // ---- children (:606-643)
             pop = true;
             if (depth < kp.max_depth - 1) {
@@ -691,7 +736,7 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int need = needed_cap(kp);
     static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
-    const bool multi = kp.spp > 1;
+    const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
            : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))

@@ -39,6 +39,9 @@ struct SceneLayout {
 #define RT_SUBQUEUES 32        // interleaved sub-queues of the persistent-wave work queue, one counter each
 #define RT_SUBQUEUE_STRIDE 64   // dwords between two counters (each on its own 256-byte line)
 #define RT_PEND_MAX 16   // pending-ray slots per lane in the global workspace (= RT_MAX_PENDING)
+#ifndef RT_MAX_LIGHT_GRID
+#define RT_MAX_LIGHT_GRID 8   // area light: at most 8 x 8 samples (as in rt355.h)
+#endif
 #define RT_QUEUE 32      // per-ray candidate queue entries (16 bits each, in LDS)
 
 static inline SceneLayout scene_layout(int n, int ntori, bool hierarchy)
@@ -87,6 +90,9 @@ struct KParams {
     int capture_seg;        // debug flavour only
     int wave_profile;       // debug flavour only: count executed code blocks per wave instead of events
     float sample_off[16];   // (i + 0.5)/spp - 0.5 for i < spp, rounded to binary32
+    int light_grid;         // G x G samples of the square area light; 1: the reference's point light
+    float inv_light;        // 1 / G^2
+    float light_off[RT_MAX_LIGHT_GRID];   // ((i + 0.5)/G - 0.5) * light_size for i < G
     SceneLayout scene;
     int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
 };

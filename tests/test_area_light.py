@@ -1,0 +1,42 @@
+"""Area light (G x G light samples per shaded hit): not a reference feature, so the oracle's
+definition is pinned by a property the reference does offer -- ray paths, sky and ambient terms
+do not depend on the light and the colour is linear in the light term, hence an area-light frame
+is, up to rounding, the mean of the G*G point-light frames (before the framebuffer clamp)."""
+import numpy as np
+import pytest
+
+
+def _light_offsets(G, size):
+    return [np.float32(np.float32((i + 0.5) / G - 0.5) * np.float32(size)) for i in range(G)]
+
+
+@pytest.mark.parametrize("G,size", [(2, 1.5), (3, 0.6)])
+def test_oracle_area_light_is_mean_of_point_lights(orc, rt, G, size):
+    scene, cam = rt.default_scene(), rt.default_camera()
+    w, h = 96, 72
+    kw = dict(max_depth=4, stack_size=3, shadow_hops=2, want_f32=True)
+    area = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, light_grid=G,
+                      light_size=size, **kw)["f32"]
+    offs = _light_offsets(G, size)
+    lx, ly, lz = (np.float32(v) for v in cam.light_pos)
+    acc = np.zeros((h, w, 4), dtype=np.float64)
+    for j in range(G):
+        for i in range(G):
+            light = (float(np.float32(lx + offs[i])), float(ly), float(np.float32(lz + offs[j])))
+            acc += orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=light, **kw)["f32"]
+    mean = acc / (G * G)
+    assert np.isfinite(area).all()
+    np.testing.assert_allclose(area[..., :3], mean[..., :3], rtol=2e-5, atol=2e-6)
+    # and it is not the point-light frame: the penumbra differs
+    point = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, **kw)["f32"]
+    assert np.abs(area - point).max() > 1e-2
+
+
+def test_oracle_light_grid_one_is_the_point_light(orc, rt):
+    scene, cam = rt.default_scene(), rt.default_camera()
+    a = orc.render(scene, cam.matrix(), cam.focal_length, 64, 48, want_f32=True)["f32"]
+    for G, size in ((0, 0.0), (1, 0.0), (1, 2.0)):
+        b = orc.render(scene, cam.matrix(), cam.focal_length, 64, 48, want_f32=True, light_grid=G, light_size=size)["f32"]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with pytest.raises(ValueError):
+        orc.render(scene, cam.matrix(), cam.focal_length, 8, 8, light_grid=9, light_size=1.0)

@@ -251,6 +251,48 @@ def test_repeated_frames_on_two_streams_are_identical(gpu_rt):
                 assert np.array_equal(got, first[gi]), (rep, gi, si)
 
 
+@pytest.mark.parametrize("case", ["default", "default_hops0", "default_deep_stack", "default_2spp", "large_scene", "tori"])
+def test_area_light_equals_oracle(gpu_rt, orc, case):
+    """G x G light samples per shaded hit (every kernel family): float32 frame, RGBA8 frame and the
+    event counters equal the oracle's, bit for bit."""
+    w, h = 120, 90
+    scene, cam = gpu_rt.default_scene(), gpu_rt.default_camera()
+    o = dict(max_depth=4, stack_size=3, shadow_hops=2, light_grid=2, light_size=1.5)
+    if case == "default_hops0":
+        o.update(shadow_hops=0, light_grid=3)
+    elif case == "default_deep_stack":
+        o.update(max_depth=8, stack_size=8, light_grid=3, light_size=0.7)
+    elif case == "default_2spp":
+        o.update(spp_grid=2)
+    elif case == "large_scene":
+        scene, cam, lo = gpu_rt.random_large_scene(7)
+        o.update(lo)
+        w, h = 96, 64
+    elif case == "tori":
+        scene, cam = gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera()
+        o.update(max_depth=3)
+        w, h = 96, 54
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, want_events=True, **o)
+    assert f32_identical(f32, ref["f32"])
+    img = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, **o)
+    assert np.array_equal(img, ref["rgba8"])
+    ev = gpu_rt.count_events(scene, cam, w, h, **o)
+    assert np.array_equal(ev, ref["events"])
+
+
+def test_area_light_parameter_limits(gpu_rt):
+    scene, cam = gpu_rt.default_scene(), gpu_rt.default_camera()
+    with pytest.raises(gpu_rt.RtError):
+        gpu_rt.render(scene, cam, 16, 16, light_grid=9, light_size=1.0)
+    with pytest.raises(gpu_rt.RtError):
+        gpu_rt.render(scene, cam, 16, 16, light_grid=2, light_size=-1.0)
+    a = gpu_rt.render_rgba(scene, cam, 64, 48, out_f32=True)
+    for G, size in ((0, 0.0), (1, 3.0)):
+        b = gpu_rt.render_rgba(scene, cam, 64, 48, out_f32=True, light_grid=G, light_size=size)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_fast_flavour_within_stated_tolerance(gpu_rt):
     meta, arr = load_golden("default_800")
     cam, scene = camera_for(meta), scene_for("default_800")

@@ -111,7 +111,7 @@ def test_library_exports_every_declared_symbol(rt):
 
 def test_struct_sizes_match_header(rt):
     assert ctypes.sizeof(rt.api.RtObject) == 64
-    assert ctypes.sizeof(rt.api.RtParams) == 16 * 4 + 4 + 12 + 4 * 6 + 4 + 8
+    assert ctypes.sizeof(rt.api.RtParams) == 16 * 4 + 4 + 12 + 4 * 6 + 4 + 8 + 8
     assert ctypes.sizeof(rt.api.RtTiming) == 20
 
 
