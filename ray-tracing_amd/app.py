@@ -305,9 +305,18 @@ def main(argv=None):
     ap.add_argument("--headless", action="store_true", help="never open a window")
     ap.add_argument("--frames", type=int, default=1, help="headless: frames to render")
     ap.add_argument("--png", default="frame_%04d.png", help="headless: output pattern")
+    # the shader's constants (fragment_shader.glsl:653, :547, :453) and the sampling extensions
+    ap.add_argument("--max-depth", type=int, default=4)
+    ap.add_argument("--stack-size", type=int, default=3)
+    ap.add_argument("--shadow-hops", type=int, default=2)
+    ap.add_argument("--spp-grid", type=int, default=1, help="N: N x N stratified samples per pixel")
+    ap.add_argument("--light-grid", type=int, default=1, help="G: G x G samples of a square area light")
+    ap.add_argument("--light-size", type=float, default=0.0, help="edge of the area light")
     args = ap.parse_args(argv)
     window = None if args.headless else open_window(args.width, args.height)
-    app = App(args.width, args.height, window=window)
+    opts = dict(max_depth=args.max_depth, stack_size=args.stack_size, shadow_hops=args.shadow_hops,
+                spp_grid=args.spp_grid, light_grid=args.light_grid, light_size=args.light_size)
+    app = App(args.width, args.height, window=window, render_opts=opts)
     if window is None:
         app.run(frames=args.frames, png_pattern=args.png)
         print(f"wrote {args.frames} frame(s) as {args.png}; {app.title}")
