@@ -205,9 +205,9 @@ def main():
             streams[1].wait_stream(streams[0])
             k0.record(stream)
             for i in range(k_steps):
-                pipe._use_stream(i)
+                pipe.use_stream(i)
                 render_part(rank, world, pipe.mine[i % 2])
-            pipe._use_stream(0)
+            pipe.use_stream(0)
             stream.wait_stream(streams[1])
             k1.record(stream)
             torch.cuda.synchronize()

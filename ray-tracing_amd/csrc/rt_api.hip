@@ -511,9 +511,7 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     LaunchInfo info{};
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
     // waits (on the GPU) for the previous one, whatever streams the two are on
-    const int pend_need = p->stack_size < p->max_depth - 1 ? p->stack_size : p->max_depth - 1;
-    const bool shares_workspace = kp.use_hierarchy != 0 || pend_need > 3 ||      // the persistent-wave kernels
-                                  (size_t)g.layout.total_dwords * 4 + 3 * 11 * 256 * 4 > 150 * 1024;
+    const bool shares_workspace = rt_uses_workspace(kp);
     if (shares_workspace && g.ws_busy && s != g.ws_stream) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)

@@ -725,16 +725,10 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     return 0;
 }
 
-static int needed_cap(const KParams &kp)
-{
-    int need = kp.stack_size < kp.max_depth - 1 ? kp.stack_size : kp.max_depth - 1;
-    return need < 1 ? 1 : need;
-}
-
 int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream, LaunchInfo *info)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int need = needed_cap(kp);
+    const RtVariantFamily family = rt_variant_family(kp);
     static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
     const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
@@ -747,12 +741,12 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
     // 2250 -> 928 ms).  The 5-object scene keeps one pixel per lane: there the lanes' loss of
     // lock-step costs more than the idle lanes (depth 8 / stack 8: 0.96 -> 1.53 ms).
-    if (kp.use_hierarchy && kp.scene.n1 > 0) {
+    if (family == RT_FAMILY_HIERARCHY) {
         // pending rays in the global workspace: 123 VGPRs whatever the stack size (register slots:
         // 147 / 168 / 256 for 3 / 7 / 16), measured 1.06-1.46x faster than register slots
         return RT_LAUNCH_HIER(RT_PEND_MAX, PEND_GLOBAL);
     }
-    if ((size_t)kp.scene.total_dwords * 4 + 3 * 11 * 256 * 4 > 150 * 1024) {
+    if (family == RT_FAMILY_WHOLE_TILES_GLOBAL) {
         // per-object loop forced on a scene whose blob leaves no LDS for pending slots
         // (RT_FLAG_NO_ACCEL with ~1000 tori): all slots in the workspace
         KParams kw = kp;
@@ -760,7 +754,7 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
         return multi ? launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, true, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info)
                      : launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, false, true>(kw, d_scene, d_out, nullptr, nullptr, s, info);
     }
-    if (need > 3) {
+    if (family == RT_FAMILY_WHOLE_TILES_HYBRID) {
         // Small scene, more than three pending rays possible: persistent waves that take whole
         // tiles (lanes stay in lock-step), slots 0-2 in LDS and the deeper ones in the global
         // workspace.  Keeps the 34 KB / 4-waves-per-SIMD footprint of the three-slot kernel

@@ -113,6 +113,30 @@ enum RtEvent {
 // Launchers, one set per numerics flavour (rt_device.hip is compiled twice).
 struct LaunchInfo { int vgprs; int lds_bytes; int pending_cap; };
 
+// Which family of kernel variants renders a frame with these parameters -- one rule, used by the
+// launchers (to pick the variant) and by the entry points (the persistent-wave variants share the
+// pending-ray workspace and the tile-queue counters, so their launches are ordered on the GPU).
+enum RtVariantFamily {
+    RT_FAMILY_ONE_PIXEL_PER_LANE,     // small scene, at most three pending rays: slots in LDS
+    RT_FAMILY_WHOLE_TILES_HYBRID,     // small scene, deeper stacks: persistent waves, slots in LDS + workspace
+    RT_FAMILY_WHOLE_TILES_GLOBAL,     // per-object loop on a scene whose blob leaves no LDS for slots
+    RT_FAMILY_HIERARCHY               // large scene: sphere hierarchy, persistent waves with per-lane refill
+};
+inline int rt_needed_pending(const KParams &kp)
+{
+    const int need = kp.stack_size < kp.max_depth - 1 ? kp.stack_size : kp.max_depth - 1;
+    return need < 1 ? 1 : need;
+}
+inline RtVariantFamily rt_variant_family(const KParams &kp)
+{
+    if (kp.use_hierarchy && kp.scene.n1 > 0) return RT_FAMILY_HIERARCHY;
+    // 3 slots x 11 dwords x 256 threads = 33 KB of LDS per workgroup next to the scene blob
+    if ((size_t)kp.scene.total_dwords * 4 + 3 * 11 * 256 * 4 > 150 * 1024) return RT_FAMILY_WHOLE_TILES_GLOBAL;
+    if (rt_needed_pending(kp) > 3) return RT_FAMILY_WHOLE_TILES_HYBRID;
+    return RT_FAMILY_ONE_PIXEL_PER_LANE;
+}
+inline bool rt_uses_workspace(const KParams &kp) { return rt_variant_family(kp) != RT_FAMILY_ONE_PIXEL_PER_LANE; }
+
 #define RT_DECLARE_FLAVOUR(NS)                                                                   \
     namespace NS {                                                                               \
     int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream,       \

@@ -125,7 +125,7 @@ class BandPipeline:
         """The most recently completed frame (rank 0; None elsewhere)."""
         return self.images[self.last_image] if self.images is not None else None
 
-    def _use_stream(self, k):
+    def use_stream(self, k):
         # self.cur: index into `streams` of the stream the callbacks are to launch on
         # (torch.cuda.current_stream() costs ~9 us a call, a table lookup by the caller nothing)
         self.cur = k % 2
@@ -133,7 +133,7 @@ class BandPipeline:
             self.torch.cuda.set_stream(self.streams[self.cur])
 
     def _finish(self, k, work):
-        self._use_stream(k)
+        self.use_stream(k)
         work.wait()
         if self.rank == 0:
             self.last_image = k % len(self.images)
@@ -146,7 +146,7 @@ class BandPipeline:
             self.render_part(0, 1, self.images[0])
             return
         buf = self.mine[k % 2]
-        self._use_stream(k)
+        self.use_stream(k)
         self.render_part(self.rank, self.world, buf)
         work = self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0, async_op=True)
         if self.prev is not None:
