@@ -368,6 +368,17 @@ def test_random_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
     assert np.array_equal(ev, ref_ev)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_with_area_light_and_samples_vs_oracle(gpu_rt, orc, seed):
+    """The same nasty small scenes with an area light (and, on odd seeds, 2 x 2 pixel samples)."""
+    scene, cam, o = gpu_rt.random_scene(seed)
+    o = dict(o, light_grid=2 + seed % 2, light_size=0.5 + 0.75 * seed, spp_grid=1 + seed % 2)
+    w, h = 96, 72
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, **o)["f32"]
+    assert f32_identical(f32, ref), f"seed {seed}: n={len(scene)} {o}"
+
+
 # ---- the sphere hierarchy used on large scenes returns the per-object loop's hits, bit for bit
 
 def _accel_vs_plain(gpu_rt, scene, cam, w, h, **o):
