@@ -215,6 +215,19 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             kernel_only_2s_ms = float(t.item())
 
+    # the transfer alone (no render, no assemble): k_steps gathers of this rank's part buffer
+    gather_only_ms = None
+    if use_dist:
+        barrier()
+        g0 = time.perf_counter()
+        for i in range(k_steps):
+            w_ = dist.gather(pipe.mine[i % 2], gather_list=pipe.chunks[i % 2] if rank == 0 else None, dst=0, async_op=True)
+            w_.wait()
+        barrier()
+        t = torch.tensor([(time.perf_counter() - g0) * 1e3 / k_steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_only_ms = float(t.item())
+
     result = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -237,6 +250,8 @@ def main():
             if kernel_only_2s_ms is not None:
                 result["kernel_only_two_streams_ms_per_step"] = kernel_only_2s_ms
             result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
+            result["gather_only_ms_per_step"] = gather_only_ms                   # transfer alone, max over ranks
+            result["part_bytes"] = int(pipe.mine[0].numel())
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
     if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
