@@ -270,9 +270,13 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
     std::vector<int> idx(n);
     for (int i = 0; i < n; ++i) idx[i] = i;
     spatial_order(objs, idx.data(), 0, n);
-    auto put_node = [&](int off, int j, const float s[4]) {
+    // A node whose members are all spheres stores its radius negated (the sign is a flag: such a
+    // node may be skipped when it lies entirely behind the ray, see trace_hierarchy).
+    auto put_node = [&](int off, int j, const float s[4], int lo, int hi) {
+        bool spheres_only = true;
+        for (int k = lo; k < hi; ++k) spheres_only = spheres_only && objs[idx[k]].type == 1;
         float *r = blob + off + 8 * (j >> 1) + (j & 1);
-        r[0] = s[0]; r[2] = s[1]; r[4] = s[2]; r[6] = s[3];
+        r[0] = s[0]; r[2] = s[1]; r[4] = s[2]; r[6] = spheres_only ? -s[3] : s[3];
     };
     float s[4], all[4];
     node_sphere(objs, idx.data(), 0, n, all);
@@ -284,13 +288,13 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
     for (int j = 0; j < L.n2; ++j) {
         int lo = j * RT_LEAF * RT_FAN, hi = std::min(n, lo + RT_LEAF * RT_FAN);
         node_sphere(objs, idx.data(), lo, hi, s);
-        put_node(L.off_top, j, s);
+        put_node(L.off_top, j, s, lo, hi);
         cover(s);
     }
     for (int j = 0; j < L.n1; ++j) {
         int lo = j * RT_LEAF, hi = std::min(n, lo + RT_LEAF);
         node_sphere(objs, idx.data(), lo, hi, s);
-        put_node(L.off_leaf, j, s);
+        put_node(L.off_leaf, j, s, lo, hi);
         cover(s);
     }
     L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
@@ -301,7 +305,8 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
         if (sl < n) {
             const float *src = blob + 8 * (idx[sl] >> 1) + (idx[sl] & 1);   // the object's own bound record
             r[0] = src[0]; r[2] = src[2]; r[4] = src[4]; r[6] = src[6];
-            slot_id[sl] = (uint16_t)idx[sl];
+            // bit 15: the object is a sphere (indices are below 1024)
+            slot_id[sl] = (uint16_t)(idx[sl] | (objs[idx[sl]].type == 1 ? 0x8000 : 0));
         } else {
             r[0] = r[2] = r[4] = 0.0f; r[6] = -INFINITY;
             slot_id[sl] = 0;

@@ -345,12 +345,26 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
 // within R + grow of g, i.e. the exact node discriminant is >= 0, and the binary32 one
 // differs from it by less than sf^2 (|oc_node|^2 + (R + grow)^2) <= slack.
 //
+//
+// Spheres behind the ray.  A sphere whose bounding test passes with b = dot(oc, d) > 0 and
+// c = dot(oc, oc) - r^2 >= 0 (origin outside, centre behind) cannot be hit: in intersect_sphere
+// (:74-92) the discriminant is RN((2b)^2) minus a non-negative product, so its root is <= 2b and
+// both quotients (-2b -+ sqrt) / 2a are <= +0, which fails t > 0.001.  An object that is not hit
+// changes nothing in the reference's loop, so such spheres are left out of the candidates (exact;
+// b < 1e15 keeps (2b)^2 finite).  Tori are never left out: the binary32 quartic solve can return
+// roots that geometry rules out.  A node whose members are all spheres (radius stored negated)
+// is skipped as a whole when its sphere, grown as above, lies behind the origin:
+// b_node > (R + grow) max(1, a).  Then every member has b > r + 0.99 grow > 0 and
+// c > 0.98 grow^2 >= 2.4e-6 reach^2, far above the rounding of either (<= 6e-7 reach^2), so each
+// of them would have been left out individually.  Used only for 0.5 < a < 2 and reach < 1e12.
+//
 // The candidates are queued per ray in LDS as 16-bit object indices; a ray that collects
 // more than RT_QUEUE of them walks all objects in step 2 instead (same result, slower).
 DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v2f DZ, float grow, float slack,
-                   bool &keep0, bool &keep1)
+                   float behind_scale, bool &keep0, bool &keep1)
 {
-    v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, R = {B.z, B.w};
+    v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y};
+    v2f R = {__builtin_fabsf(B.z), __builtin_fabsf(B.w)};
     v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
     v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
     v2f G = {grow, grow}, S = {slack, slack};
@@ -358,8 +372,12 @@ DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v
     v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
     v2f disc = b * b - (oc2 - Re * Re);
     v2f s = disc + S;
-    keep0 = !(s.x < 0.0f);
-    keep1 = !(s.y < 0.0f);
+    // behind_scale = max(1, a) for rays that may use the shortcut, +inf otherwise
+    v2f lim = Re * (v2f){behind_scale, behind_scale};
+    const bool behind0 = __builtin_signbitf(B.z) && b.x > lim.x;
+    const bool behind1 = __builtin_signbitf(B.w) && b.y > lim.y;
+    keep0 = !(s.x < 0.0f) && !behind0;
+    keep1 = !(s.y < 0.0f) && !behind1;
 }
 
 template <bool DEBUG>
@@ -379,6 +397,9 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     const float reach = (__builtin_amdgcn_sqrtf((qz * qz + qy * qy) + qx * qx) + L.hR) * 1.0001f;
     const float grow = sf * reach;
     const float slack = (sf2 * 1.05f) * (reach * reach + (reach + grow) * (reach + grow)) + 1e-30f;
+    // all-sphere nodes behind the origin are skipped, for ordinary rays only (else the limit is +inf)
+    const bool shortcut_ok = a > 0.5f && a < 2.0f && reach < 1e12f;
+    const float behind_scale = shortcut_ok ? (a > 1.0f ? a : 1.0f) * 1.0001f : __builtin_inff();
     // hl = the hierarchy sections in LDS, starting at the top nodes
     const float4 *top = reinterpret_cast<const float4 *>(hl);
     const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
@@ -393,7 +414,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     unsigned int top_mask = 0;
     for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
         bool k0, k1;
-        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
+        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, behind_scale, k0, k1);
         top_mask |= (k0 ? 1u : 0u) << (2 * j);
         top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
     }
@@ -410,7 +431,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             int lp = (first >> 1) + kk;
             lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
             bool k0, k1;
-            node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, k0, k1);
+            node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, behind_scale, k0, k1);
             bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
             bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
         }
@@ -432,13 +453,20 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             v2f c = oc2 - br2;
             v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
             v2f disc = b * b - c;
+            // (spheres that lie behind the ray are left out, see above)
             if (!(disc.x < 0.0f)) {
-                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp];
-                count++;
+                const unsigned int sid = slot_id[2 * mp];
+                if (!((sid & 0x8000u) && b.x > 0.0f && b.x < 1e15f && c.x >= 0.0f)) {
+                    if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
+                    count++;
+                }
             }
             if (!(disc.y < 0.0f)) {
-                if (count < RT_QUEUE) queue[count * 256] = slot_id[2 * mp + 1];
-                count++;
+                const unsigned int sid = slot_id[2 * mp + 1];
+                if (!((sid & 0x8000u) && b.y > 0.0f && b.y < 1e15f && c.y >= 0.0f)) {
+                    if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
+                    count++;
+                }
             }
         }
     }

@@ -59,7 +59,18 @@ def test_hierarchy_invariants(rt, which, n):
     top, _ = bound_records(blob, L["n2"], L["off_top"])
     leafn, _ = bound_records(blob, L["n1"], L["off_leaf"])
     memb, _ = bound_records(blob, L["n1"] * leaf, L["off_member"])
-    ids = blob[L["off_slot_id"]:L["off_slot_id"] + L["n1"] * leaf // 2].view(np.uint16)
+    raw_ids = blob[L["off_slot_id"]:L["off_slot_id"] + L["n1"] * leaf // 2].view(np.uint16)
+    ids = raw_ids & 0x7fff
+    # bit 15 of a slot id marks a sphere; a node of spheres only stores its radius negated
+    is_sphere = np.array([o["type"] == 1 for o in scene])
+    assert np.array_equal((raw_ids[:n] & 0x8000) != 0, is_sphere[ids[:n]])
+    for nodes, span in ((leafn, leaf), (top, leaf * fan)):
+        for j in range(len(nodes)):
+            members = ids[j * span:min(n, (j + 1) * span)]
+            assert np.signbit(nodes[j, 3]) == bool(is_sphere[members].all()), (span, j)
+    leafn, top = leafn.copy(), top.copy()
+    leafn[:, 3] = np.abs(leafn[:, 3])
+    top[:, 3] = np.abs(top[:, 3])
     # the occupied slots are a permutation of the objects and carry their own bound records
     assert sorted(ids[:n].tolist()) == list(range(n))
     assert np.array_equal(memb[:n], obj[ids[:n]])
