@@ -221,6 +221,14 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
 {
     CNT(EV_BOUND_TBOUND);
     WCNT(WP_CAND); LCNT(WP_CAND_LANES);
+    const int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
+    // A sphere behind the ray (centre behind the origin, origin outside: the sphere a reflected or
+    // shadow ray has just left, most of the time) cannot be hit: in intersect_sphere below the
+    // discriminant is RN((2b)^2) minus a non-negative product, so its root is <= 2b and both
+    // quotients are <= +0, which fails t > 0.001.  An object that is not hit changes nothing in
+    // the reference's loop, so the instrumented flavour alone goes through the motions (its
+    // counters are the reference's work).  b < 1e15 keeps (2b)^2 finite.
+    if (!DEBUG && kd < 0 && b > 0.0f && b < 1e15f && c >= 0.0f) return;
     // t_bound > closest.t can only hold once something has been hit: while closest.t is
     // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
     if (bt < 1e30f) {
@@ -228,7 +236,6 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
         float t_bound = -b - rt_sqrt(disc);
         if (t_bound > bt) return;
     }
-    int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
     float t; bool hit;
     if (kd < 0) {
         // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
