@@ -293,6 +293,67 @@ def test_area_light_parameter_limits(gpu_rt):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_band_pipeline_two_streams_rccl_one_rank(gpu_rt):
+    """The multi-GPU frame pipeline as far as one GPU can run it: a one-rank RCCL group, parts
+    travelling as RGB8 through dist.gather, frames alternating between two streams, a different
+    camera every frame.  Every delivered frame must be that camera's frame."""
+    import ctypes
+    import socket
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    tiling = import_module("ray-tracing_amd.tiling")
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        lib = gpu_rt.load_library()
+        scene = gpu_rt.default_scene()
+        gpu_rt.set_scene(scene)
+        w, h = 208, 150
+        cams = []
+        for k in range(5):
+            c = gpu_rt.default_camera()
+            c.yaw += 3.0 * k            # degrees (main.py:102-103)
+            c.pitch -= 1.5 * k
+            cams.append(c)
+        params = [gpu_rt.api.make_params(c, w, h, max_depth=6, flags=gpu_rt.api.FLAG_OUT_RGB8) for c in cams]
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        sptrs = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+        frame = {"k": 0}
+
+        def render_part(part, nparts, out):
+            p = params[frame["k"]]
+            assert lib.rt_render_device(ctypes.addressof(p), out.data_ptr(), out.numel(), sptrs[pipe.cur], 0) == 0
+
+        def assemble(gathered, image):
+            assert lib.rt_assemble_device(gathered.data_ptr(), image.data_ptr(), w, h, 1, 3, sptrs[pipe.cur]) == 0
+
+        pipe = tiling.BandPipeline(h, w, 3, torch.uint8, dev, dist, render_part, assemble, always_gather=True,
+                                   image_channels=4, streams=streams)
+        want = [gpu_rt.render_rgba(scene, c, w, h, max_depth=6) for c in cams]
+        assert all(not np.array_equal(want[k], want[k + 1]) for k in range(4))
+        # frame by frame
+        for k in range(3):
+            frame["k"] = k
+            pipe.step()
+            pipe.flush()
+            torch.cuda.synchronize()
+            assert np.array_equal(pipe.image.cpu().numpy(), want[k]), k
+        # several frames in flight: the last one delivered is the last one rendered
+        for k in range(5):
+            frame["k"] = k
+            pipe.step()
+        pipe.flush()
+        torch.cuda.synchronize()
+        assert np.array_equal(pipe.image.cpu().numpy(), want[4])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_fast_flavour_within_stated_tolerance(gpu_rt):
     meta, arr = load_golden("default_800")
     cam, scene = camera_for(meta), scene_for("default_800")
