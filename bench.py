@@ -221,8 +221,7 @@ def main():
         barrier()
         g0 = time.perf_counter()
         for i in range(k_steps):
-            w_ = dist.gather(pipe.mine[i % 2], gather_list=pipe.chunks[i % 2] if rank == 0 else None, dst=0, async_op=True)
-            w_.wait()
+            dist.gather(pipe.mine[i % 2], gather_list=pipe.chunks[i % 2] if rank == 0 else None, dst=0)
         barrier()
         t = torch.tensor([(time.perf_counter() - g0) * 1e3 / k_steps], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -69,10 +69,10 @@ def render_distributed(render_part, height: int, width: int, channels: int, dtyp
 
 
 class BandPipeline:
-    """Frames in flight over all ranks: rank r renders its bands of frame k, the gather of
-    frame k to rank 0 is started asynchronously, and frame k-1's bands are scattered into
-    the final image while frame k renders (two buffers per rank).  The only collective on
-    the data path is the gather; there is no exchange during rendering.
+    """Frames in flight over all ranks: rank r renders its bands of frame k, gathers them to
+    rank 0, which scatters the bands into the final image; with two streams frame k+1 renders
+    while frame k is in transit (two buffers per rank).  The only collective on the data path
+    is the gather; there is no exchange during rendering.
 
     render_part(part, nparts, out)   fills the (padded_rows, w, c) tensor `out` with this
                                      rank's packed bands (asynchronously on the *current*
@@ -116,7 +116,6 @@ class BandPipeline:
             self.chunks = [[g[i] for i in range(self.world)] for g in self.gathered]
         else:
             self.chunks, self.gathered = None, None
-        self.prev = None
         self.k = 0
         self.cur = 0
 
@@ -132,14 +131,8 @@ class BandPipeline:
         if self.streams is not None:
             self.torch.cuda.set_stream(self.streams[self.cur])
 
-    def _finish(self, k, work):
-        self.use_stream(k)
-        work.wait()
-        if self.rank == 0:
-            self.last_image = k % len(self.images)
-            self.assemble(self.gathered[k % 2], self.images[self.last_image])
-
     def step(self):
+        """Render, gather and (rank 0) assemble one frame; on a GPU everything is only enqueued."""
         k = self.k
         self.k += 1
         if self.direct:
@@ -148,17 +141,18 @@ class BandPipeline:
         buf = self.mine[k % 2]
         self.use_stream(k)
         self.render_part(self.rank, self.world, buf)
-        work = self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0, async_op=True)
-        if self.prev is not None:
-            self._finish(*self.prev)
-        self.prev = (k, work)
+        # A blocking-style collective: with RCCL it is enqueued like a kernel (the current stream
+        # waits for it on the GPU, the host does not), and it costs the host a fifth of an
+        # async_op=True call with a deferred wait().  Frame k+1 renders on the other stream
+        # meanwhile.
+        self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0)
+        if self.rank == 0:
+            self.last_image = k % len(self.images)
+            self.assemble(self.gathered[k % 2], self.images[self.last_image])
 
     def flush(self):
-        if self.prev is not None:
-            self._finish(*self.prev)
-            self.prev = None
+        """Leave the caller on streams[0], ordered behind everything enqueued so far."""
         if self.streams is not None:
-            # leave the caller on streams[0], ordered behind both
             self.cur = 0
             self.torch.cuda.set_stream(self.streams[0])
             self.streams[0].wait_stream(self.streams[1])
