@@ -86,6 +86,12 @@ def main():
     global W, H, MAX_DEPTH, SHADOW_HOPS
     W, H, MAX_DEPTH, SHADOW_HOPS = wl["w"], wl["h"], wl["max_depth"], wl["shadow_hops"]
 
+    # Multi-GPU runs keep several frames in flight on separate streams; HIP gives a process four
+    # hardware queues by default and streams that share a queue do not overlap, so ask for eight
+    # (read when the HIP runtime starts, i.e. before torch is imported)
+    if "RANK" in os.environ and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
     import torch
     import torch.distributed as dist
     import rt355
@@ -104,6 +110,15 @@ def main():
     # through the RCCL gather + assemble path: a rehearsal of the N > 1 code on a one-GPU box
     force_gather = os.environ.get("RT_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_gather
+    # The streams of the frame pipeline are created first, back to back: the runtime deals
+    # hardware queues to streams in creation order, and streams created later (after RCCL has
+    # made its own) ended up sharing queues, i.e. not overlapping.
+    nstreams = int(os.environ.get("RT_BENCH_STREAMS", "4")) if use_dist else 1
+    all_streams = [torch.cuda.Stream(device=dev) for _ in range(max(nstreams, 1))]
+    for s_ in all_streams:                      # first use binds a stream to its queue
+        with torch.cuda.stream(s_):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -122,12 +137,17 @@ def main():
     tch = 4 if (not use_dist or os.environ.get("RT_BENCH_RGBA_TRANSPORT") == "1") else 3
     if tch == 3:
         flags |= rt355.api.FLAG_OUT_RGB8
+    # RT_BENCH_REHEARSE_NPARTS=N (one-rank rehearsal only): every step renders part 0 of N, i.e.
+    # the kernel load of one GPU of N, through the same pipeline (the assembled frame is then
+    # meaningless and not checked)
+    rehearse_nparts = int(os.environ.get("RT_BENCH_REHEARSE_NPARTS", "0")) if (force_gather and world == 1) else 0
     params = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
-                                   shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags, part=rank, nparts=world)
+                                   shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags,
+                                   part=rank, nparts=rehearse_nparts or world)
     # a real (non-null) stream: the kernels, the RCCL hand-off and the timing events all go
     # through it (a NULL stream argument would select the library's private stream, which
     # torch events do not see)
-    stream = torch.cuda.Stream(device=dev)
+    stream = all_streams[0]
     torch.cuda.set_stream(stream)
     sptr = ctypes.c_void_p(stream.cuda_stream)
     assert stream.cuda_stream != 0
@@ -137,13 +157,13 @@ def main():
         if rc != 0:
             raise RuntimeError(lib.rt_last_error().decode())
 
-    # Split frames alternate between two streams, so that the last waves of one frame's part
-    # overlap the first waves of the next (RT_BENCH_ONE_STREAM=1 keeps them on one, for an A/B)
-    streams = None
-    if use_dist and os.environ.get("RT_BENCH_ONE_STREAM") != "1":
-        streams = [stream, torch.cuda.Stream(device=dev)]
+    # Split frames rotate over four streams, so that the last waves of a frame's part (the
+    # deepest pixels) overlap the parts of the next frames (RT_BENCH_STREAMS=1 keeps them on one
+    # stream, for an A/B).  Four streams only overlap when the process has more than HIP's
+    # default of four hardware queues: see the top of main().
+    streams = all_streams if (use_dist and nstreams > 1) else None
 
-    sptrs = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams] if streams else [sptr, sptr]
+    sptrs = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams] if streams else [sptr] * 2
 
     def cur_stream():
         return sptrs[pipe.cur]
@@ -200,15 +220,17 @@ def main():
         kernel_only_ms = float(t.item())
         kernel_only_2s_ms = None
         if streams:
-            # the same launches alternating between the two streams
+            # the same launches rotating over the streams
             barrier()
-            streams[1].wait_stream(streams[0])
             k0.record(stream)
+            for other in streams[1:]:
+                other.wait_event(k0)
             for i in range(k_steps):
                 pipe.use_stream(i)
-                render_part(rank, world, pipe.mine[i % 2])
+                render_part(rank, world, pipe.mine[i % len(streams)])
             pipe.use_stream(0)
-            stream.wait_stream(streams[1])
+            for other in streams[1:]:
+                stream.wait_stream(other)
             k1.record(stream)
             torch.cuda.synchronize()
             t = torch.tensor([k0.elapsed_time(k1) / k_steps], dtype=torch.float64, device=dev)
@@ -221,7 +243,7 @@ def main():
         barrier()
         g0 = time.perf_counter()
         for i in range(k_steps):
-            dist.gather(pipe.mine[i % 2], gather_list=pipe.chunks[i % 2] if rank == 0 else None, dst=0)
+            dist.gather(pipe.mine[i % pipe.nbuf], gather_list=pipe.chunks[i % pipe.nbuf] if rank == 0 else None, dst=0)
         barrier()
         t = torch.tensor([(time.perf_counter() - g0) * 1e3 / k_steps], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,7 +269,8 @@ def main():
         if kernel_only_ms is not None:
             result["kernel_only_ms_per_step"] = kernel_only_ms      # value above includes gather + assemble
             if kernel_only_2s_ms is not None:
-                result["kernel_only_two_streams_ms_per_step"] = kernel_only_2s_ms
+                result["kernel_only_all_streams_ms_per_step"] = kernel_only_2s_ms
+                result["streams"] = len(streams)
             result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
             result["gather_only_ms_per_step"] = gather_only_ms                   # transfer alone, max over ranks
             result["part_bytes"] = int(pipe.mine[0].numel())
@@ -304,7 +327,9 @@ def main():
             # the gathered + assembled frame must be the frame itself
             import hashlib
             golden = json.load(open(os.path.join(ROOT, "tests", "golden", "default_4k_d8s3.json")))
-            if not args.fast_math and args.stack_size == STACK_SIZE and headline:
+            if rehearse_nparts:
+                result["rehearsed_part"] = "0 of %d" % rehearse_nparts
+            elif not args.fast_math and args.stack_size == STACK_SIZE and headline:
                 got = hashlib.sha256(pipe.image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
                 result["gathered_frame_sha_ok"] = got == golden["sha256_rgba8"]
         print(json.dumps(result))

@@ -71,7 +71,7 @@ def render_distributed(render_part, height: int, width: int, channels: int, dtyp
 class BandPipeline:
     """Frames in flight over all ranks: rank r renders its bands of frame k, gathers them to
     rank 0, which scatters the bands into the final image; with two streams frame k+1 renders
-    while frame k is in transit (two buffers per rank).  The only collective on the data path
+    while frame k is in transit (one buffer set per stream).  The only collective on the data path
     is the gather; there is no exchange during rendering.
 
     render_part(part, nparts, out)   fills the (padded_rows, w, c) tensor `out` with this
@@ -96,23 +96,24 @@ class BandPipeline:
         # a world of one renders straight into the image unless the caller wants the gather
         # path exercised (tests)
         self.direct = self.world == 1 and not (always_gather and dist is not None)
-        # Two GPU streams, frame k on streams[k % 2]: the last waves of a part (a pixel's ray
-        # tree is one lane's sequential work, ~0.1 ms for the deepest pixels of the default
-        # scene, however small the part) then overlap the first waves of the next frame's part
-        # instead of leaving the GPU idle.  Everything that touches the buffers of frame k
-        # (render, hand-over to the gather, wait, assemble) is issued on streams[k % 2], so
-        # frame k+2 is ordered behind frame k's gather and assemble by stream order alone.
+        # S GPU streams, frame k on streams[k % S] with buffer set k % S: the last waves of a part
+        # (a pixel's ray tree is one lane's sequential work, ~0.1 ms for the deepest pixels of the
+        # default scene, however small the part) then overlap the next frames' parts instead of
+        # leaving the GPU idle.  Everything that touches the buffers of frame k (render, gather,
+        # assemble) is issued on streams[k % S], so frame k+S is ordered behind it by stream
+        # order alone.  (A process gets GPU_MAX_HW_QUEUES hardware queues; streams beyond that
+        # share queues and stop overlapping.)
         self.streams = list(streams) if streams else None
-        assert self.streams is None or len(self.streams) == 2
+        self.nbuf = nbuf = len(self.streams) if self.streams else 2
         rows = padded_part_rows(height, self.world)
-        self.mine = [torch.zeros((rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
-        nimg = 2 if (self.streams and not self.direct) else 1
+        self.mine = [torch.zeros((rows, width, channels), dtype=dtype, device=device) for _ in range(nbuf)]
+        nimg = nbuf if (self.streams and not self.direct) else 1
         self.images = ([torch.empty((height, width, image_channels or channels), dtype=dtype, device=device)
                         for _ in range(nimg)] if self.rank == 0 else None)
         self.last_image = 0
         if self.rank == 0 and not self.direct:
             # the gather delivers straight into the slices of one contiguous buffer per frame in flight
-            self.gathered = [torch.empty((self.world, rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
+            self.gathered = [torch.empty((self.world, rows, width, channels), dtype=dtype, device=device) for _ in range(nbuf)]
             self.chunks = [[g[i] for i in range(self.world)] for g in self.gathered]
         else:
             self.chunks, self.gathered = None, None
@@ -127,7 +128,7 @@ class BandPipeline:
     def use_stream(self, k):
         # self.cur: index into `streams` of the stream the callbacks are to launch on
         # (torch.cuda.current_stream() costs ~9 us a call, a table lookup by the caller nothing)
-        self.cur = k % 2
+        self.cur = k % self.nbuf
         if self.streams is not None:
             self.torch.cuda.set_stream(self.streams[self.cur])
 
@@ -138,21 +139,23 @@ class BandPipeline:
         if self.direct:
             self.render_part(0, 1, self.images[0])
             return
-        buf = self.mine[k % 2]
+        b = k % self.nbuf
+        buf = self.mine[b]
         self.use_stream(k)
         self.render_part(self.rank, self.world, buf)
         # A blocking-style collective: with RCCL it is enqueued like a kernel (the current stream
         # waits for it on the GPU, the host does not), and it costs the host a fifth of an
         # async_op=True call with a deferred wait().  Frame k+1 renders on the other stream
         # meanwhile.
-        self.dist.gather(buf, gather_list=self.chunks[k % 2] if self.rank == 0 else None, dst=0)
+        self.dist.gather(buf, gather_list=self.chunks[b] if self.rank == 0 else None, dst=0)
         if self.rank == 0:
             self.last_image = k % len(self.images)
-            self.assemble(self.gathered[k % 2], self.images[self.last_image])
+            self.assemble(self.gathered[b], self.images[self.last_image])
 
     def flush(self):
         """Leave the caller on streams[0], ordered behind everything enqueued so far."""
         if self.streams is not None:
             self.cur = 0
             self.torch.cuda.set_stream(self.streams[0])
-            self.streams[0].wait_stream(self.streams[1])
+            for other in self.streams[1:]:
+                self.streams[0].wait_stream(other)

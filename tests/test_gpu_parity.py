@@ -293,9 +293,9 @@ def test_area_light_parameter_limits(gpu_rt):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_band_pipeline_two_streams_rccl_one_rank(gpu_rt):
+def test_band_pipeline_streams_rccl_one_rank(gpu_rt):
     """The multi-GPU frame pipeline as far as one GPU can run it: a one-rank RCCL group, parts
-    travelling as RGB8 through dist.gather, frames alternating between two streams, a different
+    travelling as RGB8 through dist.gather, frames rotating over three streams, a different
     camera every frame.  Every delivered frame must be that camera's frame."""
     import ctypes
     import socket
@@ -321,7 +321,7 @@ def test_band_pipeline_two_streams_rccl_one_rank(gpu_rt):
             c.pitch -= 1.5 * k
             cams.append(c)
         params = [gpu_rt.api.make_params(c, w, h, max_depth=6, flags=gpu_rt.api.FLAG_OUT_RGB8) for c in cams]
-        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         sptrs = [ctypes.c_void_p(st.cuda_stream) for st in streams]
         frame = {"k": 0}
 
