@@ -124,6 +124,22 @@ size_t rt_output_bytes(const rt_params *p);
  * With timed != 0 the kernel is bracketed by hipEvents read back by rt_get_timing.       */
 int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed);
 
+/* rt_render_device for callers that cannot allocate device memory around the call (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments and result as rt_render_device(p, d_out, out_bytes, stream, 0); the
+ * tile-queue counters and the pending-ray slots that the persistent-wave kernels (scenes of 40+
+ * objects, or min(stack_size, max_depth-1) > 3) otherwise take from buffers the library allocated
+ * come from one static device array of 8 KB + RT_NOALLOC_WORKGROUPS x RT_NOALLOC_MAX_PENDING x
+ * 11 x 256 x 4 bytes (46 MB) that every GPU the library is loaded on holds until the process
+ * ends.  The call itself allocates and frees nothing.  Frames whose kernels need more than
+ * RT_NOALLOC_MAX_PENDING pending-ray slots per lane are rejected with RT_E_LIMIT.  All calls on
+ * one GPU share that array: the library orders them on the GPU in call order (one host thread, as
+ * everywhere in this API); callers that get around that order (several processes cannot: the
+ * array is per process) would race on it.                                                 */
+#define RT_NOALLOC_MAX_PENDING 4
+#define RT_NOALLOC_WORKGROUPS 1024
+int rt_render_device_noalloc(const rt_params *p, void *d_out, size_t out_bytes, void *stream);
+
 /* Convenience for host callers: rt_set_scene + render + copy to `out` (host memory),
  * blocking.  This is the call that stands where App.render's draw stood (main.py:244-303). */
 int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_t out_bytes);

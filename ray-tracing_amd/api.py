@@ -64,7 +64,8 @@ _inited_device = None
 
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
-           "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host"]
+           "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host",
+           "rt_render_device_noalloc"]
 
 
 def load_library():
@@ -83,6 +84,7 @@ def load_library():
     L.rt_output_bytes.restype = sz
     L.rt_output_bytes.argtypes = [vp]
     L.rt_render_device.argtypes = [vp, vp, sz, vp, ci]
+    L.rt_render_device_noalloc.argtypes = [vp, vp, sz, vp]
     L.rt_render.argtypes = [vp, ci, vp, vp, sz]
     L.rt_assemble_device.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.rt_get_timing.argtypes = [vp]

@@ -19,6 +19,14 @@
 #include "../../include/rt355.h"
 #include "rt_types.h"
 
+// Scratch of rt_render_device_noalloc: the tile-queue counters and a small pending-ray workspace
+// in one file-scope device array (every GPU the library is loaded on holds its own copy for the
+// life of the process).  Host code never passes this name to a kernel: rt_init looks the
+// device address up once per device (hipGetSymbolAddress) and everything uses that pointer.
+#define RT_NOALLOC_COUNTER_BYTES (RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int))
+#define RT_NOALLOC_WS_BYTES ((size_t)RT_NOALLOC_WORKGROUPS * RT_NOALLOC_MAX_PENDING * 11 * 256 * sizeof(float))
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_COUNTER_BYTES + RT_NOALLOC_WS_BYTES];
+
 namespace {
 
 struct State {
@@ -40,6 +48,9 @@ struct State {
     hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
     bool ws_busy = false;
     hipStream_t ws_stream = nullptr;
+    unsigned char *scratch_ptr = nullptr;   // device address of `scratch` on g.device
+    hipEvent_t scratch_event = nullptr;     // end of the last launch that used the static scratch
+    bool scratch_busy = false;
     rt_timing timing{};
     char err[512] = "";
 } g;
@@ -145,6 +156,7 @@ KParams make_kparams(const rt_params *p)
     k.work_counter = g.d_work;      // launches that use the queue are ordered on the GPU (workspace event)
     k.resident_workgroups = g.resident_workgroups;
     k.pend_ws = g.d_pend_ws;
+    k.pend_ws_slots = RT_PEND_MAX;
     k.light_grid = p->light_grid > 1 ? p->light_grid : 1;
     k.inv_light = 1.0f / (float)(k.light_grid * k.light_grid);
     for (int i = 0; i < RT_MAX_LIGHT_GRID; ++i)
@@ -357,6 +369,14 @@ int rt_init(int device)
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreateWithFlags(&g.ws_event, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.scratch_event, hipEventDisableTiming));
+    {
+        // device address of the static scratch array on THIS device (each GPU has its own copy)
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_E_HIP, "hipGetSymbolAddress(scratch) returned a null pointer");
+        g.scratch_ptr = static_cast<unsigned char *>(ptr);
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int)));
     {
@@ -389,6 +409,7 @@ void rt_shutdown(void)
     hipEventDestroy(g.ev0);
     hipEventDestroy(g.ev1);
     hipEventDestroy(g.ws_event);
+    hipEventDestroy(g.scratch_event);
     hipStreamDestroy(g.stream);
     g = State{};
 }
@@ -528,6 +549,41 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
         g.ws_stream = s;
     }
     if (timed) { HIP_TRY(hipEventRecord(g.ev1, s)); g.ev_pending = true; }
+    g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap;
+    return RT_OK;
+}
+
+int rt_render_device_noalloc(const rt_params *p, void *d_out, size_t out_bytes, void *stream)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (!g.have_scene) return fail(RT_E_STATE, "no scene set (rt_set_scene)");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    size_t need = rt_output_bytes(p);
+    if (!d_out && need) return fail(RT_E_ARG, "output pointer is null");
+    if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    KParams kp = make_kparams(p);
+    if (rt_uses_workspace(kp) && rt_needed_pending(kp) > RT_NOALLOC_MAX_PENDING)
+        return fail(RT_E_LIMIT, "min(stack_size, max_depth-1) = %d exceeds the %d pending-ray slots per lane of the static scratch",
+                    rt_needed_pending(kp), RT_NOALLOC_MAX_PENDING);
+    // queue counters and pending-ray slots come from the static array; the grid of the
+    // persistent-wave kernels is bounded by the workgroups the array has slices for
+    kp.work_counter = reinterpret_cast<unsigned int *>(g.scratch_ptr);
+    kp.pend_ws = reinterpret_cast<float *>(g.scratch_ptr + RT_NOALLOC_COUNTER_BYTES);
+    kp.pend_ws_slots = RT_NOALLOC_MAX_PENDING;
+    if (kp.resident_workgroups > RT_NOALLOC_WORKGROUPS) kp.resident_workgroups = RT_NOALLOC_WORKGROUPS;
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
+    // launches that use the scratch are ordered behind each other on the GPU, whatever their streams
+    const bool shares_scratch = rt_uses_workspace(kp);
+    if (shares_scratch && g.scratch_busy) HIP_TRY(hipStreamWaitEvent(s, g.scratch_event, 0));
+    LaunchInfo info{};
+    int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)
+                                             : rt_strict::launch_render(kp, g.d_scene, d_out, s, &info);
+    if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (shares_scratch) {
+        HIP_TRY(hipEventRecord(g.scratch_event, s));
+        g.scratch_busy = true;
+    }
     g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap;
     return RT_OK;
 }

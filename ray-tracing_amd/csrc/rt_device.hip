@@ -178,7 +178,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     }
     // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
     float *pend_lds = lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
-    float *pend_glb = kp.pend_ws + (size_t)blockIdx.x * (RT_PEND_MAX * 11 * 256) + threadIdx.x;
+    float *pend_glb = kp.pend_ws + (size_t)blockIdx.x * ((size_t)kp.pend_ws_slots * 11 * 256) + threadIdx.x;
     float *pend_mem = PEND == PEND_GLOBAL ? pend_glb : pend_lds;
     (void)LDSP;
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)

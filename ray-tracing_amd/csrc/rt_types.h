@@ -84,7 +84,8 @@ struct KParams {
                                   // RT_SUBQUEUE_STRIDE dwords apart, zeroed ahead of every launch
     int resident_workgroups;      // workgroups the GPU can hold at once (persistent-wave grid size)
     int whole_tiles;              // persistent waves take whole 8x8 tiles only (no per-lane refill)
-    float *pend_ws;               // pending-ray workspace: resident_workgroups x RT_PEND_MAX x 11 x 256 floats
+    float *pend_ws;               // pending-ray workspace: resident_workgroups x pend_ws_slots x 11 x 256 floats
+    int pend_ws_slots;            // slots per lane in that workspace (RT_PEND_MAX, or fewer in the static scratch)
     int out_mode;           // 0: RGBA8, 1: float4, 2: RGB8 (3 bytes per pixel, packed)
     int polish;             // Newton polish on torus roots
     int capture_seg;        // debug flavour only
