@@ -97,13 +97,22 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // of the three-slot kernel).
 enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_HYBRID_LDS_SLOTS 3      // PEND_HYBRID: slots 0..2 in LDS, the rest in the global workspace
+// Threads per workgroup.  The one-pixel-per-lane kernels with LDS slots run one wave (one 8x8 tile)
+// per workgroup: a workgroup keeps its LDS and its wave slots until its last wave ends, and ray
+// trees differ a lot between neighbouring tiles, so the three waves that finish first would leave
+// their SIMD slots empty until the fourth does.
+#ifndef RT_WG_ONE
+#define RT_WG_ONE 64
+#endif
+template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
 template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
-__global__ __launch_bounds__(256, (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
+__global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
     extern __shared__ float4 lds4[];
     float *lds = reinterpret_cast<float *>(lds4);
+    constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     const SceneLayout L = kp.scene;
     // HIER keeps only the hierarchy sections in LDS (they are what every ray reads many
     // times); bound records, materials and torus frames are read a few times per ray and
@@ -114,7 +123,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     {
         const float4 *src = reinterpret_cast<const float4 *>(scene + lds_first);
         const int nq = lds_dwords >> 2;
-        for (int i = threadIdx.x; i < nq; i += 256) lds4[i] = src[i];
+        for (int i = threadIdx.x; i < nq; i += WG) lds4[i] = src[i];
     }
     const float *sc = HIER ? scene : lds;       // bound records, materials, torus frames, kinds
     Counters<DEBUG> cnt;
@@ -136,13 +145,20 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // columns every stretch of the dispatch sequence holds the frame's mix of cheap and deep
         // tiles, and the deep ones (a centred subject) are under way early.  The image does not
         // depend on the order.
-        const int tiles_x16 = (int)gridDim.y;
-        const int k = (int)blockIdx.y, mid = tiles_x16 >> 1;
+        const int tiles_x = (int)gridDim.y;
+        const int k = (int)blockIdx.y, mid = tiles_x >> 1;
         const int bx = (k & 1) ? (mid - 1 - (k >> 1)) : (mid + (k >> 1));
-        const int by = (int)blockIdx.x;
-        px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+        int by = (int)blockIdx.x, in_band;
+        if (WG == 64) {
+            // one 8x8 tile per workgroup: two tile rows per 16-row band
+            px = bx * 8 + (lane & 7);
+            in_band = (by & 1) * 8 + (lane >> 3);
+            by >>= 1;
+        } else {
+            px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+            in_band = (wave >> 1) * 8 + (lane >> 3);
+        }
         const int band = kp.part + by * kp.nparts;
-        const int in_band = (wave >> 1) * 8 + (lane >> 3);
         const int row = band * 16 + in_band;             // output row
         packed_row = by * 16 + in_band;
         active = px < kp.w && row < kp.h;
@@ -580,11 +596,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                             q[6 * 256] = ux; q[7 * 256] = uy; q[8 * 256] = uz;
                             q[9 * 256] = n2; q[10 * 256] = __int_as_float(depth + 1);
                         } else if (MEMP) {
-                            float *q = pend_mem + slot * (11 * 256);
-                            q[0 * 256] = qx; q[1 * 256] = qy; q[2 * 256] = qz;
-                            q[3 * 256] = rx; q[4 * 256] = ry; q[5 * 256] = rz;
-                            q[6 * 256] = ux; q[7 * 256] = uy; q[8 * 256] = uz;
-                            q[9 * 256] = n2; q[10 * 256] = __int_as_float(depth + 1);
+                            float *q = pend_mem + slot * (11 * WG);
+                            q[0 * WG] = qx; q[1 * WG] = qy; q[2 * WG] = qz;
+                            q[3 * WG] = rx; q[4 * WG] = ry; q[5 * WG] = rz;
+                            q[6 * WG] = ux; q[7 * WG] = uy; q[8 * WG] = uz;
+                            q[9 * WG] = n2; q[10 * WG] = __int_as_float(depth + 1);
                         } else {
 #pragma unroll
                             for (int k = 0; k < (MEMP ? 1 : CAP); ++k) {
@@ -628,11 +644,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     thx = q[6 * 256]; thy = q[7 * 256]; thz = q[8 * 256];
                     cur_ior = q[9 * 256]; depth = __float_as_int(q[10 * 256]);
                 } else if (MEMP) {
-                    const float *q = pend_mem + slot * (11 * 256);
-                    ox = q[0 * 256]; oy = q[1 * 256]; oz = q[2 * 256];
-                    dx = q[3 * 256]; dy = q[4 * 256]; dz = q[5 * 256];
-                    thx = q[6 * 256]; thy = q[7 * 256]; thz = q[8 * 256];
-                    cur_ior = q[9 * 256]; depth = __float_as_int(q[10 * 256]);
+                    const float *q = pend_mem + slot * (11 * WG);
+                    ox = q[0 * WG]; oy = q[1 * WG]; oz = q[2 * WG];
+                    dx = q[3 * WG]; dy = q[4 * WG]; dz = q[5 * WG];
+                    thx = q[6 * WG]; thy = q[7 * WG]; thz = q[8 * WG];
+                    cur_ior = q[9 * WG]; depth = __float_as_int(q[10 * WG]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < (MEMP ? 1 : CAP); ++k) {
@@ -690,7 +706,8 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
-    if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * 256 * 4;
+    constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
+    if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     static bool attr_set = false;
@@ -704,6 +721,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;
     if (my_bands <= 0 || kp.w <= 0) return 0;
     dim3 grid(my_bands, (kp.w + 15) / 16);       // x: band of this part, y: column slot (see the kernel)
+    if (WG == 64) grid = dim3(my_bands * 2, (kp.w + 7) / 8);     // x: 8-row half band, y: 8-pixel column slot
     if (REFILL) {
         // persistent waves: no more workgroups than the queue has work for or the GPU can hold
         if (!kp.work_counter) return (int)hipErrorInvalidValue;
@@ -713,7 +731,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
         grid = dim3(wgs < 1 ? 1 : wgs, 1);
         hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(RT_SUBQUEUES), 0, stream, kp.work_counter);
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, kp, d_scene, d_out, d_ev, d_cap);
+    hipLaunchKernelGGL(kfn, grid, dim3(WG), lds, stream, kp, d_scene, d_out, d_ev, d_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (info) {
