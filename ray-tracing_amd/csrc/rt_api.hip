@@ -164,10 +164,7 @@ KParams make_kparams(const rt_params *p)
     k.out_mode = (p->flags & RT_FLAG_OUT_F32) ? 1 : (p->flags & RT_FLAG_OUT_RGB8) ? 2 : 0;
     k.polish = (p->flags & RT_FLAG_NEWTON_POLISH) ? 1 : 0;
     k.capture_seg = -1;
-    // development aid: RT_WAVE_PROFILE=1 makes rt_count_events return the wave-level block
-    // profile of the instrumented kernel (tools/wave_profile.py) instead of the event counts
-    static const bool wave_profile = getenv("RT_WAVE_PROFILE") != nullptr;
-    k.wave_profile = wave_profile ? 1 : 0;
+    k.wave_profile = 0;
     for (int i = 0; i < 16; ++i)
         k.sample_off[i] = i < p->spp_grid ? (float)(((double)i + 0.5) / (double)p->spp_grid - 0.5) : 0.0f;
     k.scene = g.layout;
@@ -176,14 +173,19 @@ KParams make_kparams(const rt_params *p)
 }
 
 // Scenes with at least this many objects get the sphere hierarchy; below it the packed
-// per-object loop is cheaper than a traversal.  RT_HIERARCHY_MIN overrides (experiments).
+// per-object loop is cheaper than a traversal.
 int hierarchy_min_objects()
 {
+#ifdef RT_DEV_SWITCHES
+    // development builds: RT_HIERARCHY_MIN overrides the threshold (experiments)
     static const int v = [] {
         const char *e = getenv("RT_HIERARCHY_MIN");
         return e ? atoi(e) : 40;
     }();
     return v;
+#else
+    return 40;
+#endif
 }
 
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
@@ -377,7 +379,7 @@ int rt_init(int device)
         if (!ptr) return fail(RT_E_HIP, "hipGetSymbolAddress(scratch) returned a null pointer");
         g.scratch_ptr = static_cast<unsigned char *>(ptr);
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), EV_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_events), RT_COUNTER_SLOTS * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_work), RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int)));
     {
         hipDeviceProp_t prop;
@@ -390,6 +392,10 @@ int rt_init(int device)
         size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
     }
+#ifdef RT_DEV_SWITCHES
+    rt_strict::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
+    rt_fast::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
+#endif
     g.device = device;
     g.inited = true;
     g.err[0] = 0;
@@ -468,6 +474,15 @@ static int pack_scene_host(const rt_object *objs, int n, SceneLayout &L_out, std
         slot++;
     }
     if (L.n1 > 0) build_hierarchy(objs, n, L, blob.data());
+    else if (n > 0) {
+        // sphere around all objects' bounding spheres: rays that miss it skip the object loop
+        std::vector<int> idx(n);
+        for (int i = 0; i < n; ++i) idx[i] = i;
+        float all[4];
+        node_sphere(objs, idx.data(), 0, n, all);
+        L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
+        L.hR = std::isfinite(all[3]) ? std::nextafter(all[3], INFINITY) : 0.0f;
+    }
     L_out = L;
     blob_out.swap(blob);
     return RT_OK;
@@ -644,7 +659,8 @@ int rt_event_count(void) { return EV_COUNT; }
 int rt_event_flops(int ev) { return (ev >= 0 && ev < EV_COUNT) ? k_event_flops[ev] : -1; }
 const char *rt_event_name(int ev) { return (ev >= 0 && ev < EV_COUNT) ? k_event_names[ev] : ""; }
 
-static int debug_launch(const rt_params *p, int seg, uint64_t *events, float *cap_host, size_t cap_bytes)
+static int debug_launch(const rt_params *p, int seg, uint64_t *events, float *cap_host, size_t cap_bytes,
+                        int wave_profile = 0)
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
     if (!g.have_scene) return fail(RT_E_STATE, "no scene set (rt_set_scene)");
@@ -652,6 +668,8 @@ static int debug_launch(const rt_params *p, int seg, uint64_t *events, float *ca
     if (rc) return rc;
     KParams kp = make_kparams(p);
     kp.capture_seg = seg;
+    kp.wave_profile = wave_profile;
+    const size_t n_counters = wave_profile ? RT_COUNTER_SLOTS : EV_COUNT;
     size_t need_cap = 0;
     float *d_cap = nullptr;
     if (cap_host) {
@@ -661,12 +679,12 @@ static int debug_launch(const rt_params *p, int seg, uint64_t *events, float *ca
         if (rc) return rc;
         d_cap = reinterpret_cast<float *>(g.d_out);
     }
-    HIP_TRY(hipMemsetAsync(g.d_events, 0, EV_COUNT * sizeof(unsigned long long), g.stream));
+    HIP_TRY(hipMemsetAsync(g.d_events, 0, RT_COUNTER_SLOTS * sizeof(unsigned long long), g.stream));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_debug(kp, g.d_scene, g.d_events, d_cap, g.stream)
                                              : rt_strict::launch_debug(kp, g.d_scene, g.d_events, d_cap, g.stream);
     if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (events)
-        HIP_TRY(hipMemcpyAsync(events, g.d_events, EV_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(events, g.d_events, n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
     if (cap_host) HIP_TRY(hipMemcpyAsync(cap_host, d_cap, need_cap, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return RT_OK;
@@ -677,6 +695,31 @@ int rt_count_events(const rt_params *p, uint64_t *events)
     if (!events) return fail(RT_E_ARG, "events pointer is null");
     return debug_launch(p, -1, events, nullptr, 0);
 }
+
+#ifdef RT_DEV_SWITCHES
+// Development builds only (not part of the product ABI): the wave-level block profile of the
+// instrumented kernel (tools/wave_profile.py), and the A/B switches of the launchers.
+int rt_wave_profile(const rt_params *p, uint64_t *counts)       // RT_COUNTER_SLOTS entries
+{
+    if (!counts) return fail(RT_E_ARG, "counts pointer is null");
+    return debug_launch(p, -1, counts, nullptr, 0, 1);
+}
+int rt_wave_profile_blocks(void) { return WP_COUNT; }
+const char *rt_wave_profile_name(int i)
+{
+    static const char *const names[WP_COUNT] = {
+#define X(n) #n,
+        RT_WAVE_PROFILE_BLOCKS(X)
+#undef X
+    };
+    return (i >= 0 && i < WP_COUNT) ? names[i] : "";
+}
+void rt_dev_switch(int which, int value)
+{
+    rt_strict::set_dev_switch(which, value);
+    rt_fast::set_dev_switch(which, value);
+}
+#endif
 
 int rt_capture_segment(const rt_params *p, int seg, float *out, size_t out_bytes)
 {

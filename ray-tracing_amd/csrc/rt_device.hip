@@ -129,7 +129,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     Counters<DEBUG> cnt;
     cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + lds_dwords);
     if constexpr (DEBUG) cnt.wave_mode = kp.wave_profile;
-    if (DEBUG) { if (threadIdx.x < EV_COUNT) cnt.lds_ev[threadIdx.x] = 0u; }
+    if (DEBUG) { if (threadIdx.x < RT_COUNTER_SLOTS) cnt.lds_ev[threadIdx.x] = 0u; }
     __syncthreads();
 
     // ---- which pixel
@@ -193,12 +193,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         pend.tx[k] = pend.ty[k] = pend.tz[k] = 0; pend.ior[k] = 1; pend.depth[k] = 0;
     }
     // LDS pending slots start after the scene (and the debug counters), 16-byte aligned
-    float *pend_lds = lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3) + threadIdx.x;
+    float *pend_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) + threadIdx.x;
     float *pend_glb = kp.pend_ws + (size_t)blockIdx.x * ((size_t)kp.pend_ws_slots * 11 * 256) + threadIdx.x;
     float *pend_mem = PEND == PEND_GLOBAL ? pend_glb : pend_lds;
     (void)LDSP;
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
-    unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? EV_COUNT : 0) + 3) & ~3)) + threadIdx.x;
+    unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3)) + threadIdx.x;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit
     float hx = 0, hy = 0, hz = 0;            // hit position
@@ -216,6 +216,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     // (i + 0.5)/N - 0.5 rounded once to binary32 (host-computed table, kp.sample_off)
     int si = 0, sj = 0;
     auto start_sample = [&]() {
+        // [census: start_sample @ START]
         // main() (:650-668): pixel centre + stratified offset
         float fx = (float)px + 0.5f, fy = (float)gy + 0.5f;
         if (MULTI) { fx = fx + kp.sample_off[si]; fy = fy + kp.sample_off[sj]; }
@@ -241,6 +242,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     const bool area_light = MULTI && kp.light_grid > 1;
     // calculate_light_attenuation set-up (:443-450) towards the current light sample
     auto setup_shadow = [&]() {
+        // [census: setup_shadow @ LOCAL]
         CNT(EV_ATTEN_FIXED);
         float qx = kp.light[0], qz = kp.light[2];
         if (area_light) { qx = qx + kp.light_off[li]; qz = qz + kp.light_off[lj]; }
@@ -255,6 +257,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     };
     // RGBA8 UNORM conversion of the framebuffer write (:674): clamp, *255, round to even
     auto write_pixel = [&]() {
+        // [census: write_pixel @ 1]
         float cr = fr, cg = fg, cb = fb;
         if (MULTI) { cr = accr * inv_spp; cg = accg * inv_spp; cb = accb * inv_spp; }
         size_t o = (size_t)packed_row * kp.w + px;
@@ -275,6 +278,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
     };
 
+    // [census: loop_control @ ITER]
     const bool in_frame = active;       // fixed pixel per lane (without REFILL)
     // wave-uniform queue state (REFILL): the tile being handed out and its next unassigned pixel
     const int tiles_x8 = (kp.w + 7) >> 3;
@@ -360,6 +364,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         do {
         if (REFILL && !active) break;
         if (SYNC && (!active || parked)) break;
+        // [census: trace_call @ ITER]
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
         if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
@@ -369,6 +374,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         bool pop = false;       // this lane needs its next ray from the pending slots
 
         if (state == ST_PATH) {
+            // [census: path_dispatch @ PATH]
             WCNT(WP_PATH); LCNT(WP_PATH_LANES);
             if (DEBUG) {
                 if (sample == 0 && seg == kp.capture_seg) { cap_id = (float)id; cap_t = id >= 0 ? t : 0.0f; cap_depth = (float)depth; }
@@ -376,6 +382,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             }
             if (id < 0) {
                 // sky (:570-580); mix(h, z, t) = h + t*(z - h); the blue channel is exactly 1
+                // [census: sky @ SKY]
                 CNT(EV_SEG_MISS);
                 WCNT(WP_SKY);
                 float tt = 0.5f + 0.5f * dy;
@@ -386,6 +393,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 fb = fb + thz;
                 pop = true;
             } else {
+                // [census: hit_info @ HIT]
                 CNT(EV_SEG_HIT);
                 WCNT(WP_HIT); LCNT(WP_HIT_LANES);
                 // ---- HitInfo of the winner (:93-100, :122-141, :357-372)
@@ -407,11 +415,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     object_centre(sc, id, qx, qy, qz);
                     int kd = reinterpret_cast<const int *>(sc + L.off_kind)[id];
                     if (kd < 0) {
+                        // [census: normal_sphere @ NORMAL_SPHERE]
                         WCNT(WP_NORMAL_SPHERE);
                         float vx = hx - qx, vy = hy - qy, vz = hz - qz;
                         float rs = rt_rsq(dot3(vx, vy, vz, vx, vy, vz));
                         nx = vx * rs; ny = vy * rs; nz = vz * rs;
                     } else {
+                        // [census: normal_torus @ NORMAL_TORUS]
                         WCNT(WP_NORMAL_TORUS);
                         TorusFrame f = load_torus(sc, L.off_torus, kd);
                         float ocx = ox - qx, ocy = oy - qy, ocz = oz - qz;
@@ -435,6 +445,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     }
                 }
                 // ---- orientation + Fresnel (:583-597, :524-534); dot(d,n) < 0 in compiled form
+                // [census: fresnel @ HIT]
                 bool entering = (dz * nz + dy * ny) < -(dx * nx);
                 osign = entering ? 1.0f : -1.0f;
                 float n1 = entering ? cur_ior : h_ior;
@@ -451,13 +462,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 float r0 = h_r0;
                 eta = entering ? h_eta_in : h_ior;
                 if (entering && cur_ior != 1.0f) {
+                    // [census: fresnel_div @ FRESNEL_DIV]
                     WCNT(WP_FRESNEL_DIV);
                     r0 = rt_div(n1 - n2, n1 + n2); r0 = r0 * r0;
                     eta = rt_div(n1, n2);
                 }
+                // [census: fresnel_pow @ FRESNEL_POW]
                 float sin_t2 = (eta * eta) * (1.0f - cos_t * cos_t);
                 if (sin_t2 > 1.0f) { CNT(EV_FRESNEL_TIR); F = 1.0f; }
                 else { CNT(EV_FRESNEL_FULL); WCNT(WP_FRESNEL_POW); F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_t, 5.0f); }
+                // [census: local_setup @ HIT]
                 local = (1.0f - m_refl) - m_transp;
                 pdx = dx; pdy = dy; pdz = dz;
                 if (local > 0.0f) {
@@ -473,13 +487,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             }
         } else {
             // ---- one shadow hop came back (:453-480)
+            // [census: shadow_hop @ SHADOW]
             WCNT(WP_SHADOW); LCNT(WP_SHADOW_LANES);
             bool lit_done = true;       // attenuation finished -> shade now
             if (id >= 0) {
                 CNT(EV_HOP_HIT_TEST);
                 float reach = t + travelled;
                 if (reach < light_dist) {
+                    // [census: hop_filter @ HOP_FILTER]
                     CNT(EV_HOP_FILTER);
+                    WCNT(WP_HOP_FILTER);
                     float cr, cg, cb, ctr;
                     if (id == L.n) {
                         // the ground is opaque (:128): whichever checker colour, colour * 0 = +0
@@ -493,7 +510,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     if ((filb * filb + filg * filg) == -(filr * filr)) {
                         filr = filg = filb = 0.0f;               // fully blocked (:468-470)
                     } else {
+                        // [census: hop_continue @ HOP_CONTINUE]
                         CNT(EV_HOP_CONTINUE);
+                        WCNT(WP_HOP_CONTINUE);
                         travelled = reach;
                         hop++;
                         if (hop < kp.hops) {
@@ -503,10 +522,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     }
                 }
             }
+            // [census: shadow_end @ SHADOW]
             if (lit_done) { spawn = true; state = ST_PATH; }
         }
 
         if (spawn) {
+            // [census: spawn @ SPAWN]
             WCNT(WP_SPAWN); LCNT(WP_SPAWN_LANES);
             if (local > 0.0f) {
                 // phong_lighting (:488-514) with attenuation = fil*, light direction = d (still L)
@@ -514,6 +535,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 float lcr = ambr, lcg = ambg, lcb = ambb;
                 // (diffuse + specular) * attenuation of the light sample the shadow hops were cast to
                 auto light_term = [&](float &tr, float &tg, float &tb) {
+                    // [census: phong @ PHONG]
                     CNT(EV_PHONG_FULL);
                     WCNT(WP_PHONG); LCNT(WP_PHONG_LANES);
                     float Lx = dx, Ly = dy, Lz = dz;
@@ -530,6 +552,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     tg = (diff * mg + spec) * filg;
                     tb = (diff * mb + spec) * filb;
                 };
+                // [census: spawn_light @ SPAWN]
                 if (!area_light) {
                     if ((filb * filb + filg * filg) != -(filr * filr)) {
                         float tr, tg, tb;
@@ -566,11 +589,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
         if (spawn) {
             // ---- children (:606-643)
+            // [census: children @ SPAWN]
             pop = true;
             if (depth < kp.max_depth - 1) {
                 WCNT(WP_CHILDREN);
                 float onx = osign * nx, ony = osign * ny, onz = osign * nz;
                 if (m_transp > 0.0f) {
+                    // [census: refract @ REFR]
                     CNT(EV_REFR_TRY);
                     WCNT(WP_REFR);
                     float k2 = 1.0f - eta * (eta * (1.0f - dni * dni));
@@ -581,6 +606,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     }
                     bool valid = -(rz * rz + ry * ry) < rx * rx;
                     if (valid && np < kp.stack_size) {
+                        // [census: refr_push @ REFR_PUSH]
                         CNT(EV_REFR_PUSH);
                         WCNT(WP_REFR_PUSH);
                         float omf = 1.0f - F;
@@ -613,11 +639,13 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         np++;
                     } else if (valid) CNT(EV_DROP);
                 }
+                // [census: reflect_eval @ CHILDREN]
                 CNT(EV_REFL_EVAL);
                 float Rt = m_refl + (1.0f - m_refl) * F;
                 if (Rt > 0.0f) {
                     if (np < kp.stack_size) {
                         // the reflection ray is the next one visited: continue with it directly
+                        // [census: reflect @ REFL]
                         CNT(EV_REFL_PUSH);
                         WCNT(WP_REFL);
                         float two_dni = dni * 2.0f;
@@ -632,8 +660,10 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
 
         if (pop) {
+            // [census: pop @ POP]
             WCNT(WP_POP);
             if (np > 0) {
+                // [census: pop_load @ POP_LOAD]
                 WCNT(WP_POP_LOAD);
                 np--;
                 const int slot = np;
@@ -660,6 +690,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 }
             } else {
                 // path finished: next stratified sample of this pixel, or done
+                // [census: finish @ FINISH]
                 WCNT(WP_FINISH);
                 if (DEBUG && sample == 0) cap_nseg = seg;
                 if (MULTI) {
@@ -679,6 +710,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     }
 
     // ---- framebuffer write
+    // [census: epilogue @ 1]
     if (!DEBUG) {
         if (!REFILL && in_frame) write_pixel();
     } else {
@@ -687,7 +719,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             cap_out[o] = cap_id; cap_out[o + 1] = cap_t; cap_out[o + 2] = cap_depth; cap_out[o + 3] = (float)cap_nseg;
         }
         __syncthreads();
-        if (ev_out && threadIdx.x < EV_COUNT) atomicAdd(&ev_out[threadIdx.x], (unsigned long long)cnt.lds_ev[threadIdx.x]);
+        if (ev_out && threadIdx.x < RT_COUNTER_SLOTS) atomicAdd(&ev_out[threadIdx.x], (unsigned long long)cnt.lds_ev[threadIdx.x]);
     }
 }
 
@@ -705,7 +737,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if ((PEND == PEND_GLOBAL || PEND == PEND_HYBRID) && !kp.pend_ws) return (int)hipErrorInvalidValue;
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
-    size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? EV_COUNT * 4 : 0);
+    size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
@@ -743,11 +775,16 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     return 0;
 }
 
+// development switch (set by the host API in -DRT_DEV_SWITCHES builds only): 1 = keep the
+// pending rays of the one-pixel-per-lane kernels in registers instead of LDS (A/B runs)
+static bool dev_no_ldsp = false;
+void set_dev_switch(int which, int value) { if (which == 0) dev_no_ldsp = value != 0; }
+
 int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream, LaunchInfo *info)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const RtVariantFamily family = rt_variant_family(kp);
-    static const bool no_ldsp = getenv("RT_NO_LDSP") != nullptr;
+    const bool no_ldsp = dev_no_ldsp;
     const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \

@@ -14,6 +14,7 @@ template <bool DEBUG> struct Counters {
     DEV void add(int) const {}
     DEV void wave(int) const {}
     DEV void lanes(int) const {}
+    DEV bool counting_events() const { return false; }
 };
 template <> struct Counters<true> {
     unsigned int *lds_ev;
@@ -27,16 +28,12 @@ template <> struct Counters<true> {
         }
     }
     DEV void lanes(int slot) const { if (wave_mode) atomicAdd(&lds_ev[slot], 1u); }
+    // the event counts are the reference's work, object by object: no shortcuts while counting
+    DEV bool counting_events() const { return !wave_mode; }
 };
 #define CNT(ev) cnt.add(ev)
 #define WCNT(slot) cnt.wave(slot)
 #define LCNT(slot) cnt.lanes(slot)
-enum { WP_ITER, WP_ITER_LANES, WP_PAIR, WP_CAND, WP_CAND_LANES, WP_TBOUND, WP_SPHERE, WP_SPHERE_LANES,
-       WP_SPHERE_ROOT2, WP_TORUS, WP_TORUS_LANES, WP_PLANE_DIV, WP_PATH, WP_PATH_LANES, WP_SKY, WP_HIT,
-       WP_HIT_LANES, WP_NORMAL_SPHERE, WP_NORMAL_TORUS, WP_FRESNEL_POW, WP_FRESNEL_DIV, WP_LOCAL, WP_SHADOW,
-       WP_SHADOW_LANES, WP_SPAWN, WP_SPAWN_LANES, WP_PHONG, WP_PHONG_LANES, WP_CHILDREN, WP_REFR, WP_REFR_PUSH,
-       WP_REFL, WP_POP, WP_POP_LOAD, WP_FINISH, WP_START, WP_COUNT };
-static_assert(WP_COUNT <= EV_COUNT, "the wave profile shares the event counter array");
 
 // ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
 #define Q_EPS 1e-7f
@@ -51,9 +48,13 @@ struct RootMin {
 template <bool DEBUG>
 DEV void quad_monic_offer(float bb, float b, float c, float offset, RootMin &rm, const Counters<DEBUG> &cnt)
 {
+    // [census: quad_monic @ QUAD_OFFER]
+    WCNT(WP_QUAD_OFFER);
     float disc = bb - 4.0f * c;
     if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); return; }
+    // [census: quad_monic_roots @ QUAD_ROOTS]
     CNT(EV_QUAD_FULL);
+    WCNT(WP_QUAD_ROOTS);
     disc = max0(disc);
     float sq = rt_sqrt(disc);
     CNT(EV_ROOT_OUT);
@@ -65,6 +66,7 @@ DEV void quad_monic_offer(float bb, float b, float c, float offset, RootMin &rm,
 template <bool DEBUG>
 DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const Counters<DEBUG> &cnt)
 {
+    // [census: quartic_depress @ TORUS]
     float a2 = a * a;
     float p = b - 0.375f * a2;
     float q = (c - (0.5f * a) * b) + (0.125f * a2) * a;
@@ -73,6 +75,8 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
     RootMin rm; rm.t = 1e20f; rm.found = false;
     if (__builtin_fabsf(q) < Q_EPS) {
         // biquadratic (:262-276): quadratic in y^2
+        // [census: biquadratic @ BIQUADRATIC]
+        WCNT(WP_BIQUADRATIC);
         float disc = p * p - 4.0f * r;
         if (disc < -Q_EPS) { CNT(EV_QUAD_EARLY); }
         else {
@@ -95,7 +99,9 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
         }
     } else {
         // resolvent cubic u^3 + 2p u^2 + (p^2 - 4r) u - q^2 (:281), first root only (:285)
+        // [census: cubic_setup @ CUBIC]
         CNT(EV_CUBIC);
+        WCNT(WP_CUBIC);
         float an = 2.0f * p;
         float bn = p * p - 4.0f * r;
         float cn = -(q * q);
@@ -108,7 +114,9 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
         float disc = half_q * half_q + rt_div_const<27>(p3);
         float u;
         if (disc >= -Q_EPS) {
+            // [census: cardano @ CARDANO]
             CNT(EV_CARDANO);
+            WCNT(WP_CARDANO); LCNT(WP_CARDANO_LANES);
             disc = max0(disc);
             float sq = rt_sqrt(disc);
             float A = -half_q + sq;
@@ -117,7 +125,9 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
             float rootB = sign_f(B) * rt_pow(__builtin_fabsf(B), 0x1.555556p-2f);
             u = (rootA - off_c) + rootB;
         } else {
+            // [census: trig @ TRIG]
             CNT(EV_TRIG);
+            WCNT(WP_TRIG); LCNT(WP_TRIG_LANES);
             float rho = rt_sqrt(rt_div_const<27>(-p3));
             float x = rt_div(-half_q, rho);
             x = (x > -1.0f) ? x : -1.0f;       // NaN -> -1
@@ -126,8 +136,10 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
             float m = 2.0f * rt_sqrt(rt_div_const<3>(-pc));
             u = m * rt_cos(theta) - off_c;
         }
+        // [census: ferrari_tail @ FERRARI_TAIL]
         if (!(u < 0.0f)) {
             CNT(EV_FERRARI_TAIL);
+            WCNT(WP_FERRARI_TAIL);
             float w = rt_sqrt(u);
             float term_A = 0.5f * (p + u);
             float term_B = rt_div(0.5f * q, w + Q_EPS);
@@ -136,6 +148,7 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
             quad_monic_offer<DEBUG>(bb, -w, term_A + term_B, offset, rm, cnt);
         }
     }
+    // [census: quartic_end @ TORUS]
     t_out = rm.t;
     return rm.found;
 }
@@ -176,6 +189,7 @@ template <bool DEBUG>
 DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, float dx, float dy, float dz,
                        int polish, float &t_out, const Counters<DEBUG> &cnt)
 {
+    // [census: torus_setup @ TORUS]
     CNT(EV_TORUS_CALL);
     float rox = dot3(ocx, ocy, ocz, f.ux, f.uy, f.uz);
     float roy = dot3(ocx, ocy, ocz, f.wx, f.wy, f.wz);
@@ -205,6 +219,9 @@ DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, flo
 
 // ------------------------------------------------------------------ trace (fragment_shader.glsl:379-435)
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef RT_SCENE_SKIP
+#define RT_SCENE_SKIP 1
+#endif
 
 // Centre of object `id` from the pair-interleaved bound records.
 DEV void object_centre(const float *lds, int id, float &cx, float &cy, float &cz)
@@ -219,6 +236,7 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
                         float ocx, float ocy, float ocz, float b, float c, float disc,
                         float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
 {
+    // [census: candidate @ CAND]
     CNT(EV_BOUND_TBOUND);
     WCNT(WP_CAND); LCNT(WP_CAND_LANES);
     const int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
@@ -232,33 +250,42 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
     // t_bound > closest.t can only hold once something has been hit: while closest.t is
     // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
     if (bt < 1e30f) {
+        // [census: t_bound @ TBOUND]
         WCNT(WP_TBOUND);
         float t_bound = -b - rt_sqrt(disc);
         if (t_bound > bt) return;
     }
+    // [census: candidate_kind @ CAND]
     float t; bool hit;
     if (kd < 0) {
         // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
+        // [census: sphere @ SPHERE]
         CNT(EV_SPHERE_CALL);
         WCNT(WP_SPHERE); LCNT(WP_SPHERE_LANES);
         float b2 = 2.0f * b;
         float ds = b2 * b2 - (4.0f * a) * c;
         hit = false; t = 0.0f;
         if (!(ds < 0.0f)) {
+            // [census: sphere_solve @ SPHERE_SOLVE]
+            WCNT(WP_SPHERE_SOLVE);
             float sq = rt_sqrt(ds);
             float two_a = 2.0f * a;
             CNT(EV_SPHERE_ROOT);
             t = rt_div(-b2 - sq, two_a);
+            // [census: sphere_root2 @ SPHERE_ROOT2]
             if (t < 0.0f) { CNT(EV_SPHERE_ROOT); WCNT(WP_SPHERE_ROOT2); t = rt_div(-b2 + sq, two_a); }
+            // [census: sphere_end @ SPHERE_SOLVE]
             hit = t > 0.001f;
             if (hit) CNT(EV_SPHERE_HIT);
         }
     } else {
+        // [census: torus_call @ TORUS]
         WCNT(WP_TORUS); LCNT(WP_TORUS_LANES);
         TorusFrame f = load_torus(lds, L.off_torus, kd);
         hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
         if (hit) CNT(EV_TORUS_HIT);
     }
+    // [census: candidate_end @ CAND]
     if (hit && t < bt) { bt = t; bid = i; }
 }
 
@@ -266,6 +293,7 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
 template <bool DEBUG>
 DEV void offer_plane(float oy, float dy, int n, float &bt, int &bid, const Counters<DEBUG> &cnt)
 {
+    // [census: plane @ ITER]
     CNT(EV_PLANE_CALL);
     bool ok = __builtin_fabsf(dy) > 0.0001f;
     if (ok) {
@@ -289,6 +317,7 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
                        float ox, float oy, float oz, float dx, float dy, float dz,
                        float &best_t, int &best_id, const Counters<DEBUG> &cnt)
 {
+    // [census: trace_setup @ ITER]
     CNT(EV_TRACE);
     float bt = 1e30f;
     int bid = -1;
@@ -296,11 +325,34 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
     const int n = L.n;
     const int npairs = (n + 1) >> 1;
+    // Rays that miss the sphere around the whole scene (L.hc, L.hR: it contains every object's
+    // bounding sphere) skip the object loop: no object's binary32 bounding test can pass for
+    // them, and an object whose test fails does nothing in the reference's loop.  The test is the
+    // node test of trace_hierarchy (see there for the bound) with the scene sphere as the node, for
+    // rays of near-unit direction (|a - 1| <= 1e-5, so sf^2 <= 2.5e-6 + 1.1e-5), and with
+    // reach = |q| + hR replaced by the larger (|q|^2 + 1)/2 + hR, which saves the square root;
+    // (reach + grow)^2 <= 1.01 reach^2.  Its own arithmetic is free to use fma: only its slack matters.
+    bool any_object = npairs > 0;
+    if (RT_SCENE_SKIP && !cnt.counting_events() && L.hR > 0.0f && n >= 3) {
+        constexpr float sf = 3.75e-3f, sf2 = 1.42e-5f;
+        const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
+        const float q2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        const float reach = __builtin_fmaf(0.5f, q2, 0.5f + L.hR) * 1.0001f;
+        const float Re = __builtin_fmaf(sf, reach, L.hR);
+        const float slack = (2.02f * sf2) * (reach * reach) + 1e-30f;
+        const float bq = __builtin_fmaf(qz, dz, __builtin_fmaf(qy, dy, qx * dx));
+        const float s = __builtin_fmaf(bq, bq, __builtin_fmaf(Re, Re, slack) - q2);
+        const bool near_unit = __builtin_fabsf(a - 1.0f) <= 1e-5f;
+        any_object = !(near_unit && s < 0.0f);       // NaN keeps the loop
+    }
     const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
     const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
     float4 A = make_float4(0, 0, 0, 0), B = A;
+    if (__ballot(any_object) == 0ull) { WCNT(WP_SCENE_SKIP); }
+    else {
     if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
     for (int j = 0; j < npairs; ++j) {
+        // [census: pair_test @ PAIR]
         WCNT(WP_PAIR);
         v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
         v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
@@ -325,11 +377,14 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
         if (!(disc.y < 0.0f))
             test_candidate<DEBUG>(lds, L, polish, 2 * j + 1, a, ocx.y, ocy.y, ocz.y, b.y, c.y, disc.y, dx, dy, dz, bt, bid, cnt);
     }
+    }
+    // [census: trace_end @ ITER]
     offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
     best_t = bt; best_id = bid;
 }
 
 // ------------------------------------------------------------------ trace through the sphere hierarchy
+// [census: hierarchy @ ITER]
 //
 // The reference's loop (:386-426) only ever acts on objects whose bounding test passes
 // (disc >= 0); for those, what it does depends on the order (the t_bound > closest.t skip and

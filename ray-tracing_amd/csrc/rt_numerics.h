@@ -78,19 +78,19 @@ DEV bool div_const_in_core_range(float x) { return ((f_bits(x) & 0x7fffffffu) - 
 template <int C> DEV float rt_div_const(float x)
 {
     if (div_const_in_core_range(x)) return div_const_core<C>(x);
-    return x / (float)C;
+    return x / (float)C;        // [census-cold]
 }
 // binary32 patterns 0x0f800000 .. 0x6f7fffff are the positive numbers in [2^-96, 2^96)
 DEV bool sqrt_in_core_range(float x) { return (f_bits(x) - 0x0f800000u) < 0x60000000u; }
 DEV float rt_sqrt(float a)
 {
     if (sqrt_in_core_range(a)) return sqrt_core(a);
-    return __builtin_sqrtf(a);
+    return __builtin_sqrtf(a);      // [census-cold]
 }
 DEV float rt_rsq(float a)
 {
     if (sqrt_in_core_range(a)) return rcp_core(sqrt_core(a));
-    return 1.0f / __builtin_sqrtf(a);
+    return 1.0f / __builtin_sqrtf(a);      // [census-cold]
 }
 #endif
 

@@ -110,6 +110,25 @@ enum RtEvent {
     EV_REFR_TRY, EV_REFR_PUSH, EV_REFL_EVAL, EV_REFL_PUSH, EV_DROP,
     EV_COUNT
 };
+#define RT_COUNTER_SLOTS 64      // counters the instrumented kernel keeps (events, or the wave profile's blocks)
+static_assert(EV_COUNT <= RT_COUNTER_SLOTS, "event counters");
+
+// Blocks of the render loop counted by the wave profile (development builds, -DRT_DEV_SWITCHES):
+// NAME counts the waves that enter the block with at least one lane, NAME_LANES the lanes.
+#define RT_WAVE_PROFILE_BLOCKS(X)                                                                    \
+    X(ITER) X(ITER_LANES) X(PAIR) X(CAND) X(CAND_LANES) X(TBOUND) X(SPHERE) X(SPHERE_LANES) X(SPHERE_SOLVE)   \
+    X(SPHERE_ROOT2) X(TORUS) X(TORUS_LANES) X(BIQUADRATIC) X(CUBIC) X(CARDANO) X(CARDANO_LANES) X(TRIG) X(TRIG_LANES) \
+    X(SCENE_SKIP) X(FERRARI_TAIL) X(QUAD_OFFER) X(QUAD_ROOTS) X(PLANE_DIV) X(PATH) X(PATH_LANES) X(SKY) X(HIT) X(HIT_LANES)  \
+    X(NORMAL_SPHERE) X(NORMAL_TORUS) X(FRESNEL_POW) X(FRESNEL_DIV) X(LOCAL) X(SHADOW) X(SHADOW_LANES)   \
+    X(HOP_FILTER) X(HOP_CONTINUE) X(SPAWN) X(SPAWN_LANES) X(PHONG) X(PHONG_LANES) X(CHILDREN) X(REFR)     \
+    X(REFR_PUSH) X(REFL) X(POP) X(POP_LOAD) X(FINISH) X(START)
+enum RtWaveProfileBlock {
+#define X(n) WP_##n,
+    RT_WAVE_PROFILE_BLOCKS(X)
+#undef X
+    WP_COUNT
+};
+static_assert(WP_COUNT <= RT_COUNTER_SLOTS, "wave profile counters");
 
 // Launchers, one set per numerics flavour (rt_device.hip is compiled twice).
 struct LaunchInfo { int vgprs; int lds_bytes; int pending_cap; };
@@ -144,6 +163,7 @@ inline bool rt_uses_workspace(const KParams &kp) { return rt_variant_family(kp) 
                       LaunchInfo *info);                                                         \
     int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events,     \
                      float *d_capture, void *stream);                                            \
+    void set_dev_switch(int which, int value);                                                   \
     }
 
 namespace rt_strict { int launch_selftest(unsigned long long *d_counts, void *stream); }
