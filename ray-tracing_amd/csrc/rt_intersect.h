@@ -222,6 +222,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef RT_SCENE_SKIP
 #define RT_SCENE_SKIP 1
 #endif
+#ifndef RT_PAIR_PACKED
+#define RT_PAIR_PACKED 0
+#endif
 
 // Centre of object `id` from the pair-interleaved bound records.
 DEV void object_centre(const float *lds, int id, float &cx, float &cy, float &cz)
@@ -345,8 +348,10 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
         const bool near_unit = __builtin_fabsf(a - 1.0f) <= 1e-5f;
         any_object = !(near_unit && s < 0.0f);       // NaN keeps the loop
     }
+#if RT_PAIR_PACKED
     const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
     const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+#endif
     float4 A = make_float4(0, 0, 0, 0), B = A;
     if (__ballot(any_object) == 0ull) { WCNT(WP_SCENE_SKIP); }
     else {
@@ -354,6 +359,7 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     for (int j = 0; j < npairs; ++j) {
         // [census: pair_test @ PAIR]
         WCNT(WP_PAIR);
+#if RT_PAIR_PACKED
         v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
         v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
         v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
@@ -364,6 +370,21 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
         A = pairs[2 * jn]; B = pairs[2 * jn + 1];
         v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
         v2f disc = b * b - c;
+#else
+        // One object per instruction: a packed FP32 instruction takes a SIMD as long as the two
+        // scalar ones it replaces, and the scalar form needs no duplicated ray operands.
+        v2f ocx, ocy, ocz, b, c, disc;
+        ocx.x = ox - A.x; ocx.y = ox - A.y; ocy.x = oy - A.z; ocy.y = oy - A.w;
+        ocz.x = oz - B.x; ocz.y = oz - B.y;
+        c.x = ((ocz.x * ocz.x + ocy.x * ocy.x) + ocx.x * ocx.x) - B.z;
+        c.y = ((ocz.y * ocz.y + ocy.y * ocy.y) + ocx.y * ocx.y) - B.w;
+        const int jn = (j + 1 < npairs) ? j + 1 : j;
+        A = pairs[2 * jn]; B = pairs[2 * jn + 1];
+        b.x = (ocz.x * dz + ocy.x * dy) + ocx.x * dx;
+        b.y = (ocz.y * dz + ocy.y * dy) + ocx.y * dx;
+        disc.x = b.x * b.x - c.x;
+        disc.y = b.y * b.y - c.y;
+#endif
         if (DEBUG) {
             const int *kind = reinterpret_cast<const int *>(lds + L.off_kind);
             if (kind[2 * j] >= 0) CNT(EV_BOUND_TORUS_RADIUS);

@@ -83,7 +83,7 @@ def child(args):
         lib.rt_get_timing(ctypes.addressof(t))
         times.append(t.kernel_ms)
     times = np.array(times[2:])
-    print(json.dumps({"lib": os.path.basename(args.lib), "config": args.config, "min_ms": float(times.min()),
+    print(json.dumps({"lib": os.path.relpath(args.lib, ROOT), "config": args.config, "min_ms": float(times.min()),
                       "median_ms": float(np.median(times)), "vgprs": t.vgprs, "cap": t.pending_cap, "sha_ok": ok,
                       "sha": hashlib.sha256(out.tobytes()).hexdigest()[:16], "no_accel": bool(args.no_accel),
                       "host_roundtrip_ms": t_host.total_ms}))
