@@ -13,7 +13,7 @@ Public surface (mirrors what the reference host owns, main.py:96-132 and :244-30
 from .camera import Camera, CameraController, camera_to_world, DEFAULT_LIGHT_POS
 from .scenes import (default_scene, default_camera, tori_stress_scene, tori_stress_camera,
                      spheres_deep_scene, spheres_deep_camera, mixed_scene, mixed_camera, random_scene,
-                     random_large_scene, sphere_row_scene)
+                     random_large_scene, sphere_row_scene, cluster_scene)
 
 from . import api
 from .api import (render, render_rgba, set_scene, init, shutdown, timing, count_events, capture_segment, selftest_math, stage_scene_host,
@@ -26,4 +26,4 @@ __all__ = ["App", "write_png", "open_window", "api", "render", "render_rgba", "s
            "Camera", "CameraController", "camera_to_world", "DEFAULT_LIGHT_POS",
            "default_scene", "default_camera", "tori_stress_scene", "tori_stress_camera",
            "spheres_deep_scene", "spheres_deep_camera", "mixed_scene", "mixed_camera", "random_scene",
-           "random_large_scene", "sphere_row_scene"]
+           "random_large_scene", "sphere_row_scene", "cluster_scene"]

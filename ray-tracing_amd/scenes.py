@@ -154,6 +154,42 @@ def random_scene(seed: int):
     return scene, cam, opts
 
 
+def cluster_scene(seed: int):
+    """3-39 objects in one compact cluster, placed and viewed so that many rays pass close to the
+    sphere around the whole cluster: the cluster may sit far from the origin (coordinates where
+    binary32 spacing is coarse), the camera far outside it, just outside it, or inside it, with a
+    wide or narrow field of view.  Returns (scene, camera, opts)."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(3, 40))
+    offset = np.array([0.0, 0.0, -4.0]) if seed % 4 else rng.uniform(-1, 1, size=3) * float(rng.choice([50.0, 600.0, 5000.0]))
+    spread = float(rng.choice([0.3, 1.0, 3.0]))
+    scene = []
+    for _ in range(n):
+        c = offset + rng.normal(size=3) * spread
+        col = rng.uniform(0.1, 1.0, size=3)
+        refl = float(rng.choice([0.0, 0.3, 0.9]))
+        transp = float(rng.choice([0.0, 0.0, 0.6]))
+        if refl + transp > 1.0:
+            transp = 0.0
+        if rng.uniform() < 0.3:
+            scene.append(_torus(c, rng.normal(size=3), rng.uniform(0.1, 0.8) * spread, rng.uniform(0.02, 0.2) * spread, col, refl, transp, 1.5))
+        else:
+            scene.append(_sphere(c, rng.uniform(0.05, 0.7) * spread, col, refl, transp, 1.5))
+    dist = float([0.0, 1.2, 3.0, 10.0][seed % 4]) * (3.0 * spread)
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction)
+    eye = offset + direction * dist + rng.normal(size=3) * 0.05
+    # look at the cluster, or a little past its edge
+    aim = offset + rng.normal(size=3) * spread * float(rng.choice([0.0, 0.7, 1.5])) - eye
+    yaw = float(np.degrees(np.arctan2(aim[2], aim[0]))) if np.hypot(aim[0], aim[2]) > 1e-6 else -90.0
+    pitch = float(np.clip(np.degrees(np.arctan2(aim[1], np.hypot(aim[0], aim[2]))), -89.0, 89.0))
+    cam = Camera(eye=tuple(_f32(v) for v in eye), yaw=_f32(yaw), pitch=_f32(pitch),
+                 focal_length=_f32(rng.choice([0.5, 2.0, 8.0]) if seed % 4 < 3 else rng.choice([2.0, 8.0])),
+                 light_pos=tuple(_f32(v) for v in (offset + rng.normal(size=3) * 4.0 * spread + np.array([0.0, 3.0 * spread, 0.0]))))
+    opts = dict(max_depth=int(rng.integers(2, 7)), stack_size=int(rng.integers(1, 5)), shadow_hops=int(rng.integers(0, 3)))
+    return scene, cam, opts
+
+
 def random_large_scene(seed: int):
     """Large random scene (100-700 objects) built to stress a spatial hierarchy: clusters of very
     different density, a few huge spheres that contain many others, objects far from the rest,

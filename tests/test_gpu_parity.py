@@ -429,6 +429,20 @@ def test_random_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
     assert np.array_equal(ev, ref_ev)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_TEST_SEEDS", "16"))))
+def test_cluster_scenes_bit_exact_vs_oracle(gpu_rt, orc, seed):
+    """Rays that miss the sphere around the whole scene skip the object loop: clusters far from the
+    origin, seen from far away, from just outside and from inside, wide and narrow fields of view."""
+    scene, cam, o = gpu_rt.cluster_scene(seed)
+    w, h = 128, 96
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, **o)["f32"]
+    assert f32_identical(f32, ref), f"seed {seed}: n={len(scene)} {o}"
+    img = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, **o)
+    ref8 = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, **o)["rgba8"]
+    assert np.array_equal(img, ref8)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scenes_with_area_light_and_samples_vs_oracle(gpu_rt, orc, seed):
     """The same nasty small scenes with an area light (and, on odd seeds, 2 x 2 pixel samples)."""
