@@ -26,6 +26,7 @@ extern "C" {
 #define RT_MAX_OBJECTS 1024   /* scene objects per frame                                 */
 #define RT_MAX_LIGHT_GRID 8   /* area light: at most 8 x 8 samples                        */
 #define RT_MAX_PENDING 16     /* min(stack_size, max_depth-1) must not exceed this       */
+#define RT_MAX_DEPTH   64     /* max_depth must not exceed this                          */
 #define RT_BAND_ROWS   16     /* rows per screen band when a frame is split over GPUs    */
 
 enum {

@@ -47,7 +47,10 @@ struct State {
     float *d_pend_ws = nullptr;         // pending-ray workspace of the persistent-wave kernels
     hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
     bool ws_busy = false;
-    hipStream_t ws_stream = nullptr;
+#ifdef RT_DEV_SWITCHES
+    unsigned long long *d_wave_log = nullptr;   // 4 words per resident wave (development builds)
+#endif
+    std::vector<rt_object> scene_objs;      // the objects of the staged scene (rt_set_scene skips an unchanged scene)
     unsigned char *scratch_ptr = nullptr;   // device address of `scratch` on g.device
     hipEvent_t scratch_event = nullptr;     // end of the last launch that used the static scratch
     bool scratch_busy = false;
@@ -100,6 +103,9 @@ int validate_params(const rt_params *p)
     if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
         return fail(RT_E_ARG, "resolution %dx%d out of range", p->width, p->height);
     if (p->max_depth < 1) return fail(RT_E_ARG, "max_depth must be >= 1");
+    // a path tree can double with every level while the stack has room: bound the depth so that
+    // one call cannot occupy the GPU for minutes
+    if (p->max_depth > RT_MAX_DEPTH) return fail(RT_E_LIMIT, "max_depth %d exceeds the limit of %d", p->max_depth, RT_MAX_DEPTH);
     if (p->stack_size < 1) return fail(RT_E_ARG, "stack_size must be >= 1");
     if (p->shadow_hops < 0 || p->shadow_hops > 64) return fail(RT_E_ARG, "shadow_hops out of range");
     if (p->spp_grid < 1 || p->spp_grid > 16) return fail(RT_E_LIMIT, "spp_grid must be 1..16");
@@ -116,6 +122,8 @@ int validate_params(const rt_params *p)
     for (int i = 0; i < 16; ++i)
         if (!std::isfinite(p->cam_to_world[i])) return fail(RT_E_ARG, "camera matrix is not finite");
     if (!std::isfinite(p->focal_length)) return fail(RT_E_ARG, "focal length is not finite");
+    for (int i = 0; i < 3; ++i)
+        if (!std::isfinite(p->light_pos[i])) return fail(RT_E_ARG, "light position is not finite");
     return 0;
 }
 
@@ -157,6 +165,9 @@ KParams make_kparams(const rt_params *p)
     k.resident_workgroups = g.resident_workgroups;
     k.pend_ws = g.d_pend_ws;
     k.pend_ws_slots = RT_PEND_MAX;
+#ifdef RT_DEV_SWITCHES
+    k.wave_log = g.d_wave_log;
+#endif
     k.light_grid = p->light_grid > 1 ? p->light_grid : 1;
     k.inv_light = 1.0f / (float)(k.light_grid * k.light_grid);
     for (int i = 0; i < RT_MAX_LIGHT_GRID; ++i)
@@ -355,6 +366,37 @@ extern "C" {
 
 const char *rt_last_error(void) { return g.err; }
 
+static void release_all()
+{
+    if (g.d_scene) (void)hipFree(g.d_scene);
+    if (g.d_out) (void)hipFree(g.d_out);
+    if (g.d_events) (void)hipFree(g.d_events);
+    if (g.d_work) (void)hipFree(g.d_work);
+    if (g.d_pend_ws) (void)hipFree(g.d_pend_ws);
+    if (g.ev0) (void)hipEventDestroy(g.ev0);
+    if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.ws_event) (void)hipEventDestroy(g.ws_event);
+    if (g.scratch_event) (void)hipEventDestroy(g.scratch_event);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    char err[sizeof g.err];
+    std::memcpy(err, g.err, sizeof err);
+    g = State{};
+    std::memcpy(g.err, err, sizeof err);
+}
+
+// The pending-ray workspace of the persistent-wave kernels (184 MB on a 256-CU GPU), allocated
+// when the first scene or frame that needs it arrives.
+static int ensure_workspace()
+{
+    if (g.d_pend_ws) return 0;
+    static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
+    size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
+    return 0;
+}
+
+static int init_device(int device);
+
 int rt_init(int device)
 {
     if (g.inited) {
@@ -366,6 +408,13 @@ int rt_init(int device)
     if (e != hipSuccess || count <= 0)
         return fail(RT_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
     if (device < 0 || device >= count) return fail(RT_E_ARG, "device %d out of range (0..%d)", device, count - 1);
+    int rc = init_device(device);
+    if (rc) release_all();       // nothing half-made stays behind
+    return rc;
+}
+
+static int init_device(int device)
+{
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
@@ -386,13 +435,9 @@ int rt_init(int device)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         // the persistent-wave kernels run at up to 4 waves per SIMD = 4 workgroups per CU
         g.resident_workgroups = prop.multiProcessorCount * 4;
-        // pending-ray workspace of the persistent-wave kernels, sliced by resident workgroup
-        // (184 MB on a 256-CU GPU)
-        static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
-        size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
     }
 #ifdef RT_DEV_SWITCHES
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_wave_log), (size_t)g.resident_workgroups * 4 * 4 * sizeof(unsigned long long)));
     rt_strict::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
     rt_fast::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
 #endif
@@ -405,19 +450,10 @@ int rt_init(int device)
 void rt_shutdown(void)
 {
     if (!g.inited) return;
-    hipSetDevice(g.device);
-    hipStreamSynchronize(g.stream);
-    if (g.d_scene) hipFree(g.d_scene);
-    if (g.d_out) hipFree(g.d_out);
-    if (g.d_events) hipFree(g.d_events);
-    if (g.d_work) hipFree(g.d_work);
-    if (g.d_pend_ws) hipFree(g.d_pend_ws);
-    hipEventDestroy(g.ev0);
-    hipEventDestroy(g.ev1);
-    hipEventDestroy(g.ws_event);
-    hipEventDestroy(g.scratch_event);
-    hipStreamDestroy(g.stream);
-    g = State{};
+    (void)hipSetDevice(g.device);
+    (void)hipDeviceSynchronize();
+    release_all();
+    g.err[0] = 0;
 }
 
 // Validation + staging of a scene on the host: the blob the kernels read and its layout.
@@ -491,6 +527,11 @@ static int pack_scene_host(const rt_object *objs, int n, SceneLayout &L_out, std
 int rt_set_scene(const rt_object *objs, int n)
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    // the same objects as the staged scene (a viewer re-submits its scene every frame, as
+    // main.py:283-296 re-uploads the uniforms): nothing to do
+    if (g.have_scene && n >= 0 && (size_t)n == g.scene_objs.size() &&
+        (n == 0 || (objs && std::memcmp(objs, g.scene_objs.data(), (size_t)n * sizeof(rt_object)) == 0)))
+        return RT_OK;
     SceneLayout L;
     std::vector<float> blob;
     int rc = pack_scene_host(objs, n, L, blob);
@@ -509,6 +550,8 @@ int rt_set_scene(const rt_object *objs, int n)
     HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
     g.layout = L;
     g.have_scene = true;
+    g.scene_objs.assign(objs, objs + n);
+    if (L.n1 > 0) return ensure_workspace();     // large scenes render as persistent waves
     return RT_OK;
 }
 
@@ -553,7 +596,14 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
     // waits (on the GPU) for the previous one, whatever streams the two are on
     const bool shares_workspace = rt_uses_workspace(kp);
-    if (shares_workspace && g.ws_busy && s != g.ws_stream) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
+    if (shares_workspace && !g.d_pend_ws) {
+        // first frame that needs the pending-ray workspace (deep stack on a small scene)
+        int wrc = ensure_workspace();
+        if (wrc) return wrc;
+        kp.pend_ws = g.d_pend_ws;
+    }
+    // (a wait on an event recorded on the same stream costs nothing on the GPU)
+    if (shares_workspace && g.ws_busy) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)
                                              : rt_strict::launch_render(kp, g.d_scene, d_out, s, &info);
@@ -561,7 +611,6 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     if (shares_workspace) {
         HIP_TRY(hipEventRecord(g.ws_event, s));
         g.ws_busy = true;
-        g.ws_stream = s;
     }
     if (timed) { HIP_TRY(hipEventRecord(g.ev1, s)); g.ev_pending = true; }
     g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap;
@@ -714,6 +763,20 @@ const char *rt_wave_profile_name(int i)
     };
     return (i >= 0 && i < WP_COUNT) ? names[i] : "";
 }
+// per persistent wave of the last render: start, end (100 MHz ticks), loop trips, pixels finished
+int rt_dev_wave_log(uint64_t *out, int max_waves)
+{
+    if (!g.inited || !out) return fail(RT_E_ARG, "bad wave log arguments");
+    int n = g.resident_workgroups * 4 < max_waves ? g.resident_workgroups * 4 : max_waves;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, g.d_wave_log, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
+int rt_dev_wave_log_clear(void)
+{
+    HIP_TRY(hipMemset(g.d_wave_log, 0, (size_t)g.resident_workgroups * 4 * 4 * sizeof(unsigned long long)));
+    return RT_OK;
+}
 void rt_dev_switch(int which, int value)
 {
     rt_strict::set_dev_switch(which, value);
@@ -774,7 +837,7 @@ int rt_assemble_device(const void *d_gathered, void *d_image, int width, int hei
                        int bytes_per_pixel, void *stream)
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
-    if (!d_gathered || !d_image || width <= 0 || height <= 0 || nparts < 1 ||
+    if (!d_gathered || !d_image || width <= 0 || height <= 0 || width > 32768 || height > 32768 || nparts < 1 ||
         (bytes_per_pixel != 3 && bytes_per_pixel != 4 && bytes_per_pixel != 16))
         return fail(RT_E_ARG, "bad assemble arguments");
     // every part's buffer is padded to the size of part 0 (the largest), as a gather of

@@ -279,6 +279,10 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     };
 
     // [census: loop_control @ ITER]
+#ifdef RT_DEV_SWITCHES
+    const unsigned long long dev_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dev_trips = 0, dev_pixels = 0;
+#endif
     const bool in_frame = active;       // fixed pixel per lane (without REFILL)
     // wave-uniform queue state (REFILL): the tile being handed out and its next unassigned pixel
     const int tiles_x8 = (kp.w + 7) >> 3;
@@ -361,6 +365,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // One trace + shading step of the lanes that have a pixel.  Idle lanes skip forward to
         // the end of the loop body (never `continue`: a back edge taken by idle lanes alone
         // would let them spin in a loop of their own while the busy lanes wait to reconverge).
+#ifdef RT_DEV_SWITCHES
+        dev_trips++;
+#endif
         do {
         if (REFILL && !active) break;
         if (SYNC && (!active || parked)) break;
@@ -704,11 +711,24 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     active = false;
                 }
                 if (REFILL && !active) write_pixel();
+#ifdef RT_DEV_SWITCHES
+                if (REFILL && !active) dev_pixels++;
+#endif
             }
         }
         } while (false);
     }
 
+#ifdef RT_DEV_SWITCHES
+    if (REFILL && kp.wave_log) {
+        unsigned long long px_done = dev_pixels;
+        for (int o = 32; o > 0; o >>= 1) px_done += __shfl_xor(px_done, o);
+        if (lane == 0) {
+            unsigned long long *w = kp.wave_log + ((size_t)blockIdx.x * 4 + wave) * 4;
+            w[0] = dev_t0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = dev_trips; w[3] = px_done;
+        }
+    }
+#endif
     // ---- framebuffer write
     // [census: epilogue @ 1]
     if (!DEBUG) {
@@ -742,12 +762,15 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is kept per device: set it again when this variant first runs on another one
+    static int attr_device = -1;
+    int cur_device = -1;
+    if (hipGetDevice(&cur_device) != hipSuccess) return (int)hipErrorInvalidDevice;
+    if (attr_device != cur_device) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_device = cur_device;
     }
     int bands = (kp.h + 15) / 16;
     int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;

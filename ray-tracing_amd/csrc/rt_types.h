@@ -96,6 +96,9 @@ struct KParams {
     float light_off[RT_MAX_LIGHT_GRID];   // ((i + 0.5)/G - 0.5) * light_size for i < G
     SceneLayout scene;
     int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
+#ifdef RT_DEV_SWITCHES
+    unsigned long long *wave_log;   // development builds: per persistent wave {start, end (100 MHz ticks), loop trips, pixels}
+#endif
 };
 
 // ---- work events (same classes, same weights as the shader-source FLOP convention) ----
