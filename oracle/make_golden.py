@@ -189,6 +189,42 @@ def spp_case(name, N, check_oracle):
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), rgb32f=np.ascontiguousarray(mean[..., :3]))
 
 
+def light_case(name, G, size, check_oracle):
+    """Square area light, G x G samples: the reference has one point light (main.py:278), but its
+    ray paths, sky and ambient terms do not depend on the light and the colour is linear in the
+    (diffuse + specular) * attenuation term (fragment_shader.glsl:513, :603).  The fixture is the
+    mean (float64, stored as float32) of the G*G unclamped RGBA32F frames the reference shader
+    renders with u_light_pos at the G*G sample positions; an area-light frame equals it up to
+    rounding."""
+    scene = rt355.default_scene()
+    cam = rt355.default_camera()
+    w, h = 160, 120
+    M = rt355.camera_to_world(cam.eye, cam.yaw, cam.pitch)
+    prog = lp.Program(len(scene), 4, 3, 2)
+    prog.set_scene(scene)
+    offs = [np.float32(np.float32((i + 0.5) / G - 0.5) * np.float32(size)) for i in range(G)]
+    lx, ly, lz = (np.float32(v) for v in cam.light_pos)
+    acc = np.zeros((h, w, 4), dtype=np.float64)
+    for j in range(G):
+        for i in range(G):
+            light = (float(np.float32(lx + offs[i])), float(ly), float(np.float32(lz + offs[j])))
+            prog.set_camera(M, cam.focal_length, w, h, light)
+            acc += prog.draw_rgba32f(w, h)
+    mean = (acc / (G * G)).astype(np.float32)
+    meta = {"name": name, "w": w, "h": h, "light_grid": G, "light_size": size, "max_depth": 4, "stack_size": 3,
+            "shadow_hops": 2, "camera": cam_dict(cam), "sha256_rgb32f": sha(mean[..., :3]), "row_order": "bottom-up"}
+    msg = f"{name}: light {G}x{G}, edge {size}"
+    if check_oracle:
+        o = orc.render(scene, M, cam.focal_length, w, h, light=cam.light_pos, light_grid=G, light_size=size, want_f32=True)["f32"]
+        err = np.abs(o[..., :3].astype(np.float64) - mean[..., :3])
+        msg += f" | oracle max abs difference {err.max():.3g}, max relative {np.max(err / np.maximum(np.abs(mean[..., :3]), 1e-3)):.3g}"
+        meta["oracle_check"] = {"max_abs_difference": float(err.max())}
+    print(msg, flush=True)
+    with open(os.path.join(GOLDEN, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), rgb32f=np.ascontiguousarray(mean[..., :3]))
+
+
 def quartic_kats(check_oracle):
     """Known answers for solve_quartic (fragment_shader.glsl:250-305): the reference's solver
     functions with a test main() that evaluates them on uniform coefficient sets."""
@@ -277,6 +313,9 @@ def main():
     if not args.only or "spp" in args.only:
         spp_case("spp2_200", 2, args.check_oracle)
         spp_case("spp4_200", 4, args.check_oracle)
+    if not args.only or "light" in args.only:
+        light_case("light2_160", 2, 1.5, args.check_oracle)
+        light_case("light3_160", 3, 0.6, args.check_oracle)
     if not args.only or "quartic_kats" in args.only:
         quartic_kats(args.check_oracle)
 

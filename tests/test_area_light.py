@@ -1,9 +1,41 @@
-"""Area light (G x G light samples per shaded hit): not a reference feature, so the oracle's
-definition is pinned by a property the reference does offer -- ray paths, sky and ambient terms
-do not depend on the light and the colour is linear in the light term, hence an area-light frame
-is, up to rounding, the mean of the G*G point-light frames (before the framebuffer clamp)."""
+"""Area light (G x G light samples per shaded hit): not a reference feature, but pinned by the
+reference all the same -- ray paths, sky and ambient terms do not depend on the light and the
+colour is linear in the light term, hence an area-light frame is, up to rounding, the mean of the
+G*G point-light frames (before the framebuffer clamp).  tests/golden/light*_160 hold that mean of
+frames the reference shader itself rendered on llvmpipe with u_light_pos at the sample positions
+(oracle/make_golden.py: light_case); the oracle must agree with it to a few units in the last
+place, and the HIP kernels equal the oracle bit for bit (tests/test_gpu_parity.py)."""
 import numpy as np
 import pytest
+
+from conftest import camera_for, load_golden
+
+# |area-light frame - mean of the reference's point-light frames|: both sum G*G light terms of
+# magnitude <= ~2 in binary32, in different orders -> a few ulp of the largest term
+LIGHT_ABS_TOL = 1.5e-6
+
+
+@pytest.mark.parametrize("name", ["light2_160", "light3_160"])
+def test_oracle_area_light_equals_mean_of_reference_frames(orc, rt, name):
+    meta, arr = load_golden(name)
+    cam = camera_for(meta)
+    o = orc.render(rt.default_scene(), cam.matrix(), cam.focal_length, meta["w"], meta["h"], light=cam.light_pos,
+                   light_grid=meta["light_grid"], light_size=meta["light_size"], max_depth=meta["max_depth"],
+                   stack_size=meta["stack_size"], shadow_hops=meta["shadow_hops"], want_f32=True)["f32"]
+    ref = arr["rgb32f"]
+    assert np.isfinite(ref).all() and ref.max() > 0.5
+    assert np.abs(o[..., :3].astype(np.float64) - ref).max() <= LIGHT_ABS_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["light2_160", "light3_160"])
+def test_gpu_area_light_equals_mean_of_reference_frames(gpu_rt, name):
+    meta, arr = load_golden(name)
+    cam = camera_for(meta)
+    f32 = gpu_rt.render_rgba(gpu_rt.default_scene(), cam, meta["w"], meta["h"], bottom_up=True, out_f32=True,
+                             light_grid=meta["light_grid"], light_size=meta["light_size"], max_depth=meta["max_depth"],
+                             stack_size=meta["stack_size"], shadow_hops=meta["shadow_hops"])
+    assert np.abs(f32[..., :3].astype(np.float64) - arr["rgb32f"]).max() <= LIGHT_ABS_TOL
 
 
 def _light_offsets(G, size):

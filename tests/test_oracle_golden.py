@@ -8,7 +8,7 @@ import pytest
 
 from conftest import camera_for, golden_names, load_golden, scene_for
 
-FRAME_CASES = [n for n in golden_names() if not n.startswith("spp")]
+FRAME_CASES = [n for n in golden_names() if not n.startswith(("spp", "light"))]
 SMALL = [n for n in FRAME_CASES if "4k" not in n]
 
 
