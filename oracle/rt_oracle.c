@@ -59,7 +59,9 @@ typedef struct {
     int32_t spp_grid;        /* N: N x N stratified samples per pixel; 1 = reference */
     int32_t light_grid;      /* G: G x G samples of a square area light; 0 or 1 = the reference's point light */
     float light_size;        /* edge of that square (horizontal, centred on `light`) */
+    uint32_t flags;          /* ORC_FLAG_* */
 } orc_params;
+#define ORC_FLAG_NEWTON_POLISH 1u   /* not the reference: polish torus roots, drop roots that are not on the torus */
 
 /* ---- work counters (events), used for the algorithmic FLOP total ---- */
 enum {
@@ -270,6 +272,7 @@ typedef struct {
     int light_grid;                         /* > 1: area light, see phong() */
     float light_off[ORC_MAX_LIGHT_GRID];    /* offset of sample column/row i from the light's centre */
     float inv_light;                        /* 1 / (light_grid * light_grid) */
+    int polish;                             /* ORC_FLAG_NEWTON_POLISH */
 } scene_ctx;
 
 /* intersect_sphere, fragment_shader.glsl:74-103 */
@@ -415,8 +418,54 @@ int orc_solve_quartic(float a, float b, float c, float d, float *roots)
     return solve_quartic(a, b, c, d, roots, NULL);
 }
 
+/*
+ * Newton polish of a torus root (NOT part of the reference, whose solve ends with Ferrari's roots,
+ * fragment_shader.glsl:345-352; optional, ORC_FLAG_NEWTON_POLISH).  The quartic's coefficients are
+ * differences of terms of size |ro|^4, so in binary32 its roots are off by 1e-4..1e-2 of t and some
+ * are not intersections at all.  The polish leaves the polynomial and works on the torus itself,
+ * in its own frame: g(p) = (rho - R)^2 + y^2 - r^2 with rho = sqrt(x^2 + z^2) is zero on the
+ * surface and well conditioned near it.  Five Newton steps on g(ro + t rd), each at most r long;
+ * the best of the six points visited replaces the root if it is past 0.001 and within 4r of
+ * the start (it cannot wander to another crossing of the tube), otherwise the root stays.  A root
+ * whose best |g| is still above 0.01 r^2 does not lie on the torus: the hit is dropped.
+ * Returns 1 with *t updated, or 0 for "no intersection".  Plain binary32 operations in this order;
+ * the HIP kernel (rt_intersect.h: torus_polish) runs the same sequence.
+ */
+static float torus_g(v3 ro, v3 rd, float R, float r2, float t, float *dg)
+{
+    float px = ro.x + t * rd.x, py = ro.y + t * rd.y, pz = ro.z + t * rd.z;
+    float rho = sqrtf(px * px + pz * pz);
+    float a = rho - R;
+    float g = (a * a + py * py) - r2;
+    *dg = 2.0f * (a * ((px * rd.x + pz * rd.z) / rho) + py * rd.y);
+    return g;
+}
+#ifndef ORC_POLISH_STEPS
+#define ORC_POLISH_STEPS 5
+#define ORC_POLISH_WINDOW 4.0f
+#endif
+static int torus_polish(v3 ro, v3 rd, float R, float r, float *t_io)
+{
+    const float r2 = r * r, t0 = *t_io;
+    float t = t0, dg;
+    float g = torus_g(ro, rd, R, r2, t, &dg);
+    float best_t = t0, best_g = fabsf(g);
+    for (int it = 0; it < ORC_POLISH_STEPS; ++it) {
+        if (!(fabsf(dg) > 0.0f)) break;                 /* zero or NaN slope */
+        float step = g / dg;
+        step = step > r ? r : step;
+        step = step < -r ? -r : step;
+        t = t - step;
+        g = torus_g(ro, rd, R, r2, t, &dg);
+        if (fabsf(g) < best_g) { best_g = fabsf(g); best_t = t; }
+    }
+    if (best_t > 0.001f && fabsf(best_t - t0) <= ORC_POLISH_WINDOW * r) *t_io = best_t;
+    else best_g = fabsf(torus_g(ro, rd, R, r2, t0, &dg));
+    return best_g <= 0.01f * r2;                        /* false for NaN */
+}
+
 /* intersect_torus, fragment_shader.glsl:309-375 */
-static int intersect_torus(ray_t ray, const orc_object *s, hit_t *h, counters *cnt)
+static int intersect_torus(ray_t ray, const orc_object *s, hit_t *h, counters *cnt, int polish)
 {
     CNT(EV_TORUS_CALL);
     v3 c = V(s->center[0], s->center[1], s->center[2]);
@@ -447,6 +496,7 @@ static int intersect_torus(ray_t ray, const orc_object *s, hit_t *h, counters *c
     for (int i = 0; i < nr; ++i)
         if (roots[i] > 0.001f && roots[i] < t) { t = roots[i]; found = 1; }
     if (!found) return 0;
+    if (polish && !torus_polish(ro, rd, R, r, &t)) return 0;
     CNT(EV_TORUS_HIT);
     h->hit = 1; h->t = t;
     h->pos = vadd(ray.o, vscale(ray.d, t));
@@ -482,7 +532,7 @@ static hit_t trace(const scene_ctx *sc, ray_t ray, counters *cnt)
         if (t_bound > best.t) continue;
         hit_t cur; cur.hit = 0;
         if (s->type == 1) intersect_sphere(ray, s, &cur, cnt);
-        else intersect_torus(ray, s, &cur, cnt);
+        else intersect_torus(ray, s, &cur, cnt, sc->polish);
         if (cur.hit && cur.t < best.t) { best = cur; best.id = i; }
     }
     hit_t ph; ph.hit = 0;
@@ -706,6 +756,7 @@ static void make_ctx(scene_ctx *sc, const orc_object *objs, int n, const orc_par
     for (int i = 0; i < ORC_MAX_LIGHT_GRID; ++i)
         sc->light_off[i] = i < sc->light_grid ? sample_offset(i, sc->light_grid) * p->light_size : 0.0f;
     sc->inv_light = 1.0f / (float)(sc->light_grid * sc->light_grid);
+    sc->polish = (p->flags & ORC_FLAG_NEWTON_POLISH) ? 1 : 0;
 }
 
 

@@ -26,7 +26,7 @@ class OrcParams(ctypes.Structure):
     _fields_ = [("cam_to_world", ctypes.c_float * 16), ("focal", ctypes.c_float), ("light", ctypes.c_float * 3),
                 ("w", ctypes.c_int32), ("h", ctypes.c_int32), ("max_depth", ctypes.c_int32),
                 ("stack_size", ctypes.c_int32), ("shadow_hops", ctypes.c_int32), ("spp_grid", ctypes.c_int32),
-                ("light_grid", ctypes.c_int32), ("light_size", ctypes.c_float)]
+                ("light_grid", ctypes.c_int32), ("light_size", ctypes.c_float), ("flags", ctypes.c_uint32)]
 
 
 _lib = None
@@ -77,8 +77,9 @@ def pack_scene(scene):
 
 
 def make_params(cam_to_world, focal, w, h, light=(-2.0, 4.0, 1.0), max_depth=4, stack_size=3,
-                shadow_hops=2, spp_grid=1, light_grid=1, light_size=0.0):
+                shadow_hops=2, spp_grid=1, light_grid=1, light_size=0.0, newton_polish=False):
     p = OrcParams()
+    p.flags = 1 if newton_polish else 0
     m = np.ascontiguousarray(cam_to_world, dtype=np.float32).ravel()
     p.cam_to_world[:] = m.tolist()
     p.focal = float(focal)
@@ -97,11 +98,12 @@ def event_table():
 
 def render(scene, cam_to_world, focal, w, h, *, light=(-2.0, 4.0, 1.0), max_depth=4, stack_size=3,
            shadow_hops=2, spp_grid=1, light_grid=1, light_size=0.0, want_f32=False, want_events=False, rows=None,
-           nthreads=None):
+           nthreads=None, newton_polish=False):
     """Returns dict(rgba8=(h,w,4) uint8 bottom-up [, f32=(h,w,4) float32][, events=uint64[EV_COUNT]])."""
     L = lib()
     objs = pack_scene(scene)
-    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, spp_grid, light_grid, light_size)
+    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, spp_grid, light_grid, light_size,
+                    newton_polish)
     y0, y1 = (0, h) if rows is None else rows
     nrows = y1 - y0
     u8 = np.empty((nrows, w, 4), dtype=np.uint8)
@@ -123,11 +125,11 @@ def render(scene, cam_to_world, focal, w, h, *, light=(-2.0, 4.0, 1.0), max_dept
 
 
 def capture(scene, cam_to_world, focal, w, h, seg, *, light=(-2.0, 4.0, 1.0), max_depth=4, stack_size=3,
-            shadow_hops=2, nthreads=None):
+            shadow_hops=2, nthreads=None, newton_polish=False):
     """(h,w,4) float32: id, t, depth, segment count for segment `seg` of each pixel's path."""
     L = lib()
     objs = pack_scene(scene)
-    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, 1)
+    p = make_params(cam_to_world, focal, w, h, light, max_depth, stack_size, shadow_hops, 1, newton_polish=newton_polish)
     out = np.empty((h, w, 4), dtype=np.float32)
     if nthreads is None:
         nthreads = min(os.cpu_count() or 1, 16)

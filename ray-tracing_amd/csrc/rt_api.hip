@@ -506,7 +506,7 @@ static int pack_scene_host(const rt_object *objs, int n, SceneLayout &L_out, std
         t[0] = u[0]; t[1] = u[1]; t[2] = u[2]; t[3] = w[0];
         t[4] = w[1]; t[5] = w[2]; t[6] = v[0]; t[7] = v[1];
         t[8] = v[2]; t[9] = R; t[10] = R * R; t[11] = r * r;
-        t[12] = (4.0f * R) * R; t[13] = (8.0f * R) * R;
+        t[12] = (4.0f * R) * R; t[13] = (8.0f * R) * R; t[14] = r;
         slot++;
     }
     if (L.n1 > 0) build_hierarchy(objs, n, L, blob.data());

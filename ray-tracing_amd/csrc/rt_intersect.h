@@ -153,7 +153,7 @@ DEV bool quartic_nearest(float a, float b, float c, float d, float &t_out, const
     return rm.found;
 }
 
-struct TorusFrame { float ux, uy, uz, wx, wy, wz, vx, vy, vz, R, R2, r2, fourR2, eightR2; };
+struct TorusFrame { float ux, uy, uz, wx, wy, wz, vx, vy, vz, R, R2, r2, fourR2, eightR2, r; };
 
 DEV TorusFrame load_torus(const float *lds, int off_torus, int slot)
 {
@@ -163,25 +163,47 @@ DEV TorusFrame load_torus(const float *lds, int off_torus, int slot)
     f.ux = a.x; f.uy = a.y; f.uz = a.z; f.wx = a.w;
     f.wy = b.x; f.wz = b.y; f.vx = b.z; f.vy = b.w;
     f.vz = c.x; f.R = c.y; f.R2 = c.z; f.r2 = c.w;
-    f.fourR2 = d.x; f.eightR2 = d.y;
+    f.fourR2 = d.x; f.eightR2 = d.y; f.r = d.z;
     return f;
 }
 
-// Two Newton steps on the selected root; kept only if the residual shrinks.
-DEV float newton_polish(float A, float B, float C, float D, float t)
+// Newton polish of a torus root (not part of the reference, whose solve ends with Ferrari's roots,
+// :345-352; RT_FLAG_NEWTON_POLISH).  The quartic's coefficients are differences of terms of size
+// |ro|^4, so in binary32 its roots are off by 1e-4..1e-2 of t and some are no intersections at
+// all.  The polish leaves the polynomial and works on the torus itself, in its own frame:
+// g(p) = (rho - R)^2 + y^2 - r^2, rho = sqrt(x^2 + z^2), is zero on the surface and well
+// conditioned near it.  Five Newton steps on g(ro + t rd), each at most r long; the best of the
+// six points visited replaces the root if it is past 0.001 and within 4r of the start (it cannot
+// wander to another crossing of the tube), otherwise the root stays.  A root whose best |g| is
+// still above 0.01 r^2 does not lie on the torus: the hit is dropped.  Plain binary32 operations
+// in the order of the CPU oracle's torus_polish, so the strict flavour equals it bit for bit.
+DEV float torus_g(float rox, float roy, float roz, float rdx, float rdy, float rdz, float R, float r2, float t, float &dg)
 {
-    float t0 = t;
-    float f0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t, 1.0f, A), t, B), t, C), t, D);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        float f = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
-        float df = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(4.0f, t, 3.0f * A), t, 2.0f * B), t, C);
-        float step = f * __builtin_amdgcn_rcpf(df);
+    float px = rox + t * rdx, py = roy + t * rdy, pz = roz + t * rdz;
+    float rho = rt_sqrt(px * px + pz * pz);
+    float a = rho - R;
+    float g = (a * a + py * py) - r2;
+    dg = 2.0f * (a * rt_div(px * rdx + pz * rdz, rho) + py * rdy);
+    return g;
+}
+DEV bool torus_polish(float rox, float roy, float roz, float rdx, float rdy, float rdz, float R, float r, float &t_io)
+{
+    const float r2 = r * r, t0 = t_io;
+    float t = t0, dg;
+    float g = torus_g(rox, roy, roz, rdx, rdy, rdz, R, r2, t, dg);
+    float best_t = t0, best_g = __builtin_fabsf(g);
+    for (int it = 0; it < 5; ++it) {
+        if (!(__builtin_fabsf(dg) > 0.0f)) break;                 // zero or NaN slope
+        float step = rt_div(g, dg);
+        step = step > r ? r : step;
+        step = step < -r ? -r : step;
         t = t - step;
+        g = torus_g(rox, roy, roz, rdx, rdy, rdz, R, r2, t, dg);
+        if (__builtin_fabsf(g) < best_g) { best_g = __builtin_fabsf(g); best_t = t; }
     }
-    float f1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t + A, t, B), t, C), t, D);
-    bool ok = __builtin_fabsf(f1) < __builtin_fabsf(f0) && t > 0.001f;
-    return ok ? t : t0;
+    if (best_t > 0.001f && __builtin_fabsf(best_t - t0) <= 4.0f * r) t_io = best_t;
+    else best_g = __builtin_fabsf(torus_g(rox, roy, roz, rdx, rdy, rdz, R, r2, t0, dg));
+    return best_g <= 0.01f * r2;                                  // false for NaN
 }
 
 // intersect_torus (:309-352) up to the root; ocx.. = ray origin - centre.
@@ -212,7 +234,7 @@ DEV bool torus_nearest(const TorusFrame &f, float ocx, float ocy, float ocz, flo
     float D = k * k - f.fourR2 * ro_dxz;
     float t;
     bool found = quartic_nearest<DEBUG>(A, B, C, D, t, cnt);
-    if (found && polish) t = newton_polish(A, B, C, D, t);
+    if (found && polish) found = torus_polish(rox, roy, roz, rdx, rdy, rdz, f.R, f.r, t);
     t_out = t;
     return found;
 }

@@ -10,7 +10,7 @@
 //                                      FP32 math; br = bounding_radius^2; np = ceil(n/2); an odd n
 //                                      is padded with a record whose br is -inf (never passes)
 //   [.., + 8n)           material[i] = { r, g, b, reflectivity } { transparency, ior, r0, 1/ior }: r0 = ((1-ior)/(1+ior))^2
-//   [.., + 16*nt)        torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 0 0 }
+//   [.., + 16*nt)        torus[s]    = { ux uy uz wx } { wy wz vx vy } { vz R R^2 r^2 } { 4R^2 8R^2 r 0 }
 //   [.., + n)            kind[i]     = -1 for a sphere, torus slot s >= 0 for a torus
 // Large scenes add a two-level hierarchy of bounding spheres over the objects' bounding
 // spheres (objects sorted into spatial order; a leaf node holds RT_LEAF consecutive slots, a
