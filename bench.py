@@ -46,8 +46,13 @@ WORKLOADS = {
     "mixed1024_8k": dict(scene="mixed", w=7680, h=4320, max_depth=8, stack_size=8, shadow_hops=2, spp_grid=4,
                          text="1024 mixed objects, 7680x4320, 16 spp, max_depth 8, stack_size %(stack_size)d, 2 shadow hops"),
 }
-PEAK_FP32_VECTOR_TFLOPS = 157.3     # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
-PEAK_FP32_FMA_TFLOPS = 78.6         # same without packed math
+# 256 CU x 4 SIMD x 32 lanes per clock x 2 (FMA) x 2.4 GHz: a SIMD issues one wave64 v_fma_f32 every
+# 2 cycles; v_pk_fma_f32 takes 4, so packed math reaches the same peak, not twice it
+# (tools/microbench/valu_rate, profiles/r2/valu_issue_rates_mi355x.txt)
+PEAK_FP32_VECTOR_TFLOPS = 157.3
+# the same lanes executing one operation per instruction (add, mul; the reference's arithmetic is
+# separately rounded, so the strict flavour cannot fuse): 78.6 T lane-operations/s
+PEAK_FP32_LANE_OPS_T = 78.6
 
 
 def hbm_traffic_bytes(args):
@@ -62,6 +67,31 @@ def hbm_traffic_bytes(args):
         return None
     try:
         return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def executed_work(workload, fast_math):
+    """What the hardware executed, from the committed rocprofv3 counter summary of this workload's
+    render kernel (profiles/r*/pmc_<workload>.json, tools/prof_workload.py): VALU lane-operations
+    per launch = SQ_INSTS_VALU x 64 x VALUUtilization, their rate over that launch's own duration
+    against the 78.6 T lane-operations/s of the chip, VALUBusy and the active-lane fraction.
+    Unlike the algorithmic figure it cannot exceed 1 and does not credit work a spatial hierarchy
+    avoids.  None when no summary is committed for the workload."""
+    if fast_math:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.json" % workload)))
+    if not files:
+        return None
+    try:
+        c = json.load(open(files[-1]))
+        lane_ops = c["SQ_INSTS_VALU"] * 64.0 * c["VALUUtilization"] / 100.0
+        secs = c["kernel_ms"] * 1e-3
+        return {"valu_lane_ops_per_launch": lane_ops, "rate_T_per_s": lane_ops / secs / 1e12,
+                "frac_of_lane_rate": lane_ops / secs / 1e12 / PEAK_FP32_LANE_OPS_T,
+                "valu_busy_pct": c["VALUBusy"], "valu_utilization_pct": c["VALUUtilization"],
+                "kernel_ms_profiled": c["kernel_ms"], "source": os.path.relpath(files[-1], ROOT)}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -292,13 +322,19 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         result["roofline"] = {
             "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "frac_of_unpacked_fma_peak": achieved / PEAK_FP32_FMA_TFLOPS,
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "frac_of_lane_op_rate": achieved / PEAK_FP32_LANE_OPS_T,
             "traffic": hbm_traffic_bytes(args),
             "kernel": "rt_kernel<%d,false> (%s)" % (tim.pending_cap, "fast" if args.fast_math else "strict"),
             "kernel_ms_avg": kernel_ms, "kernel_ms_single_launch": tim.kernel_ms,
             "algorithmic_flops_per_frame": flops, "flops_per_pixel_path": flops / (W * H * wl["spp_grid"] ** 2),
             "vgprs": tim.vgprs, "lds_bytes": tim.lds_bytes,
         }
+        if wl["scene"] != "default":
+            result["roofline"]["note"] = ("algorithmic FLOPs count the reference's per-object loop (every object's bounding test "
+                                          "per ray); the sphere hierarchy does not execute most of them: see `executed`")
+        ex = executed_work(args.workload, args.fast_math)
+        if ex:
+            result["roofline"]["executed"] = ex
         traffic = result["roofline"]["traffic"]
         if traffic:
             # the memory side of the same launch, to show which roof is the near one
@@ -306,7 +342,9 @@ def main():
             result["roofline"]["hbm"] = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0}
         if not args.no_cpu_baseline and headline:
             import rt_oracle as orc
-            threads = min(os.cpu_count() or 1, 16)
+            # the host cores this job may use: the box sets OMP_NUM_THREADS to its share of the machine
+            host_cpus = os.cpu_count() or 1
+            threads = min(int(os.environ.get("OMP_NUM_THREADS", host_cpus)), host_cpus)
             frames = 0
             orc.render(scene, cam.matrix(), cam.focal_length, W, H // 8, max_depth=MAX_DEPTH,
                        stack_size=args.stack_size, shadow_hops=SHADOW_HOPS, nthreads=threads)   # warm up
@@ -317,14 +355,14 @@ def main():
                 frames += 1
             cpu_s = (time.perf_counter() - c0) / frames
             result["cpu_baseline"] = {
-                "value": W * H / 1e6 / cpu_s, "unit": "Mpixel-paths/s", "cores": threads, "kind": "port",
-                "sample": "%d full 3840x2160 frames of the same workload (%.2f s each) on %d OpenMP threads"
-                          % (frames, cpu_s, threads),
+                "value": W * H / 1e6 / cpu_s, "unit": "Mpixel-paths/s", "cores": threads, "host_cpus": host_cpus, "kind": "port",
+                "sample": "%d full 3840x2160 frames of the same workload (%.2f s each) on %d OpenMP threads "
+                          "(OMP_NUM_THREADS; the machine has %d CPUs)" % (frames, cpu_s, threads, host_cpus),
             }
 
     if rank == 0:
-        if force_gather:
-            # the gathered + assembled frame must be the frame itself
+        if use_dist:
+            # the gathered + assembled frame must be the frame itself (every N > 1 run checks itself)
             import hashlib
             golden = json.load(open(os.path.join(ROOT, "tests", "golden", "default_4k_d8s3.json")))
             if rehearse_nparts:

@@ -598,6 +598,10 @@ def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
         scene, cam, w, h, o = gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera(), 960, 540, dict(max_depth=8, stack_size=8, shadow_hops=2)
     if os.environ.get("RT_HEAVY_FULL") == "1":       # one-off: the full benchmark sizes (minutes of CPU time)
         w, h = (1920, 1080) if which == "mixed1024_16spp" else (3840, 2160)
+    elif os.environ.get("RT_HEAVY_FULL") != "0":
+        # the default run: the 64 tori at their full 3840x2160; the two configurations whose CPU
+        # oracle needs minutes at full size stay at a quarter of it (RT_HEAVY_FULL=1 runs them whole)
+        w, h = {"tori64_d8s8": (3840, 2160), "spheres256_d16": (1920, 1080), "mixed1024_16spp": (960, 540)}[which]
     f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
     ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, want_f32=True, **o)["f32"]
     assert f32_identical(f32, ref)
