@@ -71,11 +71,13 @@ def hbm_traffic_bytes(args):
         return None
 
 
-def executed_work(workload, fast_math):
+def executed_work(workload, fast_math, kernel_ms):
     """What the hardware executed, from the committed rocprofv3 counter summary of this workload's
     render kernel (profiles/r*/pmc_<workload>.json, tools/prof_workload.py): VALU lane-operations
-    per launch = SQ_INSTS_VALU x 64 x VALUUtilization, their rate over that launch's own duration
-    against the 78.6 T lane-operations/s of the chip, VALUBusy and the active-lane fraction.
+    per launch = SQ_INSTS_VALU x 64 x VALUUtilization (instruction counts do not change from launch
+    to launch), their rate over the kernel time measured in this run (launches under the counter
+    collection itself run 1.0-1.4x longer) against the 78.6 T lane-operations/s of the chip, VALUBusy
+    (gfx94x formula: 4 cycles per instruction, so it passes 100 % on gfx950) and the active-lane fraction.
     Unlike the algorithmic figure it cannot exceed 1 and does not credit work a spatial hierarchy
     avoids.  None when no summary is committed for the workload."""
     if fast_math:
@@ -87,7 +89,7 @@ def executed_work(workload, fast_math):
     try:
         c = json.load(open(files[-1]))
         lane_ops = c["SQ_INSTS_VALU"] * 64.0 * c["VALUUtilization"] / 100.0
-        secs = c["kernel_ms"] * 1e-3
+        secs = kernel_ms * 1e-3
         return {"valu_lane_ops_per_launch": lane_ops, "rate_T_per_s": lane_ops / secs / 1e12,
                 "frac_of_lane_rate": lane_ops / secs / 1e12 / PEAK_FP32_LANE_OPS_T,
                 "valu_busy_pct": c["VALUBusy"], "valu_utilization_pct": c["VALUUtilization"],
@@ -332,7 +334,7 @@ def main():
         if wl["scene"] != "default":
             result["roofline"]["note"] = ("algorithmic FLOPs count the reference's per-object loop (every object's bounding test "
                                           "per ray); the sphere hierarchy does not execute most of them: see `executed`")
-        ex = executed_work(args.workload, args.fast_math)
+        ex = executed_work(args.workload, args.fast_math, kernel_ms)
         if ex:
             result["roofline"]["executed"] = ex
         traffic = result["roofline"]["traffic"]

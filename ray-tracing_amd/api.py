@@ -65,7 +65,7 @@ _inited_device = None
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
            "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host",
-           "rt_render_device_noalloc"]
+           "rt_render_device_noalloc", "rt_host_alloc", "rt_host_free"]
 
 
 def load_library():
@@ -86,6 +86,9 @@ def load_library():
     L.rt_render_device.argtypes = [vp, vp, sz, vp, ci]
     L.rt_render_device_noalloc.argtypes = [vp, vp, sz, vp]
     L.rt_render.argtypes = [vp, ci, vp, vp, sz]
+    L.rt_host_alloc.argtypes = [sz]
+    L.rt_host_alloc.restype = vp
+    L.rt_host_free.argtypes = [vp]
     L.rt_assemble_device.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.rt_get_timing.argtypes = [vp]
     L.rt_count_events.argtypes = [vp, vp]
@@ -122,8 +125,44 @@ def _ensure_init():
 def shutdown():
     global _inited_device
     if _lib is not None and _inited_device is not None:
+        for _, ptr in _pinned:
+            _lib.rt_host_free(ptr)
+        _pinned.clear()
         _lib.rt_shutdown()
     _inited_device = None
+
+
+_pinned = []      # (array, address) pairs handed out by pinned_empty
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """A numpy array in page-locked host memory (rt_host_alloc), for `render(..., out=array)`: the
+    frame then comes back in one DMA transfer (at 3840x2160 the read-back, not the kernel, is most
+    of a frame's time).  The memory belongs to the library: it is gone after pinned_release(array)
+    or shutdown(), and the array must not be used afterwards."""
+    L = _ensure_init()
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    ptr = L.rt_host_alloc(nbytes)
+    if not ptr:
+        raise RtError(-5, L.rt_last_error().decode(errors="replace"))
+    raw = (ctypes.c_uint8 * max(nbytes, 1)).from_address(ptr)
+    a = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    _pinned.append((a, ptr))
+    return a
+
+
+def is_pinned(a) -> bool:
+    return any(b is a for b, _ in _pinned)
+
+
+def pinned_release(a):
+    """Give an array from pinned_empty back (do not touch it afterwards)."""
+    for i, (b, ptr) in enumerate(_pinned):
+        if b is a:
+            _check(_lib.rt_host_free(ptr))
+            del _pinned[i]
+            return
 
 
 _SCENE_KEYS = {"type", "center", "radius", "normal", "major_radius", "minor_radius", "color", "reflectivity",
@@ -189,7 +228,7 @@ def set_scene(scene):
 
 def _render_host(scene, camera, w, h, channels, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
                  fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
-                 no_accel=False, light_grid=1, light_size=0.0):
+                 no_accel=False, light_grid=1, light_size=0.0, out=None):
     L = _ensure_init()
     arr = pack_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
@@ -199,7 +238,11 @@ def _render_host(scene, camera, w, h, channels, *, max_depth=4, stack_size=3, sh
     nbytes = L.rt_output_bytes(ctypes.addressof(p))
     bpp = 16 if out_f32 else channels
     rows = nbytes // (bpp * int(w)) if w > 0 else 0
-    out = np.empty((rows, int(w), channels), dtype=np.float32 if out_f32 else np.uint8)
+    want = ((rows, int(w), channels), np.dtype(np.float32 if out_f32 else np.uint8))
+    if out is None:
+        out = np.empty(*want)
+    elif out.shape != want[0] or out.dtype != want[1] or not out.flags.c_contiguous:
+        raise RtError(-1, f"out must be a C-contiguous {want[1]} array of shape {want[0]}")
     _check(L.rt_render(ctypes.addressof(arr), len(scene), ctypes.addressof(p), out.ctypes.data, out.nbytes))
     return out
 
@@ -220,7 +263,9 @@ def render(scene, camera, w, h, **opts) -> np.ndarray:
     scene : list of dicts exactly as the reference's App.scene (main.py:125-132)
     camera: Camera or dict(eye, yaw, pitch, focal_length[, light_pos]) (main.py:102-109, :278)
     opts  : max_depth=4, stack_size=3, shadow_hops=2 (the constants of fragment_shader.glsl:653,
-            :547, :453), spp_grid=1, fast_math=False, newton_polish=False
+            :547, :453), spp_grid=1, fast_math=False, newton_polish=False,
+            out=array from pinned_empty((h, w, 3)) to receive the frame (a frame loop should pass one:
+            page-locked memory halves the time of a 4K frame)
 
     The kernel writes packed RGB8 (the reference's alpha is the constant 1.0), so the read-back
     is three bytes per pixel.

@@ -47,9 +47,24 @@ def write_png(path, image) -> None:
                 chunk(b"IEND", b""))
 
 
+_frame_buffers = {}
+
+
 def _gpu_renderer(scene, camera, w, h, **opts):
+    """The HIP path into a page-locked frame buffer that is reused from frame to frame (like the
+    reference's back buffer, main.py:303, the previous frame is gone once the next one is drawn)."""
     from . import api
-    return api.render_rgba(scene, camera, w, h, **opts)
+    key = (int(h), int(w), bool(opts.get("out_f32")))
+    if key not in _frame_buffers and not opts.get("nparts", 1) > 1:
+        for old in _frame_buffers.values():         # a resized window: one buffer at a time
+            api.pinned_release(old)
+        _frame_buffers.clear()
+        _frame_buffers[key] = api.pinned_empty((int(h), int(w), 4), np.float32 if key[2] else np.uint8)
+    buf = _frame_buffers.get(key)
+    if buf is not None and not api.is_pinned(buf):     # the library was shut down meanwhile: the memory is gone
+        del _frame_buffers[key]
+        return _gpu_renderer(scene, camera, w, h, **opts)
+    return api.render_rgba(scene, camera, w, h, out=buf, **opts)
 
 
 class App:

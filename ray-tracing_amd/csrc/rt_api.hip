@@ -672,6 +672,22 @@ int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_
     return RT_OK;
 }
 
+void *rt_host_alloc(size_t bytes)
+{
+    if (!g.inited) { fail(RT_E_STATE, "rt_init has not been called"); return nullptr; }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(RT_E_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int rt_host_free(void *buf)
+{
+    if (!buf) return RT_OK;
+    HIP_TRY(hipHostFree(buf));
+    return RT_OK;
+}
+
 int rt_get_timing(rt_timing *t)
 {
     if (!t) return fail(RT_E_ARG, "timing pointer is null");
