@@ -110,6 +110,24 @@ typedef struct rt_timing {
  * one GPU, creates the render stream and loads the kernels.                              */
 int rt_init(int device);
 
+/* One process, several GPUs (no counterpart: the reference draws on one GPU).  After
+ * rt_init_multi(n) the same calls -- rt_set_scene, rt_render, rt_render_device with part/nparts
+ * 0/1 -- use devices 0..n-1: the scene is staged on each, device i renders the RT_BAND_ROWS-row
+ * bands b with b % n == i, and each device copies its bands straight into the frame on device 0
+ * (strided device-to-device copies over xGMI; no gather buffer, no assemble pass), where
+ * rt_render reads it back / rt_render_device leaves it in the caller's buffer, the caller's
+ * stream waiting for all parts.  rt_init_multi_devices takes the device of every part explicitly;
+ * a device may appear more than once (its parts then share that GPU), which is also how the
+ * multi-part path is exercised on a machine with one GPU.  Kernel timing (timed != 0), the event
+ * counters and rt_render_device_noalloc stay single-device features of device 0.            */
+int rt_init_multi(int n_devices);
+int rt_init_multi_devices(const int *devices, int n);
+int rt_device_count(void);        /* parts a frame is split into: 0 before rt_init, 1 after rt_init */
+
+/* Host-only helper (no GPU): the output row of every packed row of part `part` of `nparts`, in
+ * buffer order; returns their number (rows may be NULL to ask for it).                       */
+int rt_part_row_map(int height, int part, int nparts, int32_t *rows, int capacity);
+
 /* Replaces cleanup (main.py:350-355).                                                    */
 void rt_shutdown(void);
 

@@ -17,12 +17,12 @@ from .scenes import (default_scene, default_camera, tori_stress_scene, tori_stre
 
 from . import api
 from .api import (render, render_rgba, set_scene, init, shutdown, timing, count_events, capture_segment, selftest_math, stage_scene_host,
-                  frame_flops, event_table, load_library, RtError, pinned_empty)
+                  frame_flops, event_table, load_library, RtError, pinned_empty, init_multi)
 
 from .app import App, write_png, open_window
 
 __all__ = ["App", "write_png", "open_window", "api", "render", "render_rgba", "set_scene", "init", "shutdown", "timing", "count_events",
-           "capture_segment", "selftest_math", "stage_scene_host", "frame_flops", "event_table", "load_library", "RtError", "pinned_empty",
+           "capture_segment", "selftest_math", "stage_scene_host", "frame_flops", "event_table", "load_library", "RtError", "pinned_empty", "init_multi",
            "Camera", "CameraController", "camera_to_world", "DEFAULT_LIGHT_POS",
            "default_scene", "default_camera", "tori_stress_scene", "tori_stress_camera",
            "spheres_deep_scene", "spheres_deep_camera", "mixed_scene", "mixed_camera", "random_scene",

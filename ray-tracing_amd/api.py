@@ -65,7 +65,8 @@ _inited_device = None
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output_bytes", "rt_render_device",
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
            "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host",
-           "rt_render_device_noalloc", "rt_host_alloc", "rt_host_free"]
+           "rt_render_device_noalloc", "rt_host_alloc", "rt_host_free", "rt_init_multi", "rt_init_multi_devices", "rt_device_count",
+           "rt_part_row_map"]
 
 
 def load_library():
@@ -86,6 +87,9 @@ def load_library():
     L.rt_render_device.argtypes = [vp, vp, sz, vp, ci]
     L.rt_render_device_noalloc.argtypes = [vp, vp, sz, vp]
     L.rt_render.argtypes = [vp, ci, vp, vp, sz]
+    L.rt_init_multi.argtypes = [ci]
+    L.rt_init_multi_devices.argtypes = [vp, ci]
+    L.rt_part_row_map.argtypes = [ci, ci, ci, vp, ci]
     L.rt_host_alloc.argtypes = [sz]
     L.rt_host_alloc.restype = vp
     L.rt_host_free.argtypes = [vp]
@@ -114,6 +118,31 @@ def init(device: int = 0):
     _check(L.rt_init(int(device)))
     _inited_device = int(device)
     return L
+
+
+def init_multi(n_devices=None, devices=None):
+    """One process, several GPUs: frames of render()/render_rgba() are split into interleaved
+    16-row bands over `devices` (default: 0..n_devices-1) and put together on the first one."""
+    global _inited_device
+    L = load_library()
+    if devices is None:
+        _check(L.rt_init_multi(int(n_devices)))
+        devices = list(range(int(n_devices)))
+    else:
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        _check(L.rt_init_multi_devices(arr, len(devices)))
+    _inited_device = int(devices[0])
+    return L
+
+
+def part_row_map(height, part, nparts):
+    L = load_library()
+    n = L.rt_part_row_map(int(height), int(part), int(nparts), None, 0)
+    if n < 0:
+        raise RtError(n, L.rt_last_error().decode(errors="replace"))
+    rows = np.zeros(max(n, 1), dtype=np.int32)
+    L.rt_part_row_map(int(height), int(part), int(nparts), rows.ctypes.data, n)
+    return rows[:n]
 
 
 def _ensure_init():

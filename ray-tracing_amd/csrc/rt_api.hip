@@ -51,6 +51,20 @@ struct State {
     unsigned long long *d_wave_log = nullptr;   // 4 words per resident wave (development builds)
 #endif
     std::vector<rt_object> scene_objs;      // the objects of the staged scene (rt_set_scene skips an unchanged scene)
+    // rt_init_multi: one context per part of the frame.  Part i is rendered on parts[i].device into
+    // its own packed buffer and copied from there, band by band, into the frame on the first device.
+    struct Part {
+        int device = -1;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;          // this part's bands are in the frame
+        hipEvent_t frame_free = nullptr;    // recorded on the frame's stream: the frame may be overwritten
+        float *d_scene = nullptr; size_t d_scene_cap = 0;
+        void *d_part = nullptr; size_t d_part_cap = 0;
+        unsigned int *d_work = nullptr;
+        float *d_pend_ws = nullptr;
+        int resident_workgroups = 0;
+    };
+    std::vector<Part> parts;                // empty: single-device mode
     unsigned char *scratch_ptr = nullptr;   // device address of `scratch` on g.device
     hipEvent_t scratch_event = nullptr;     // end of the last launch that used the static scratch
     bool scratch_busy = false;
@@ -366,8 +380,27 @@ extern "C" {
 
 const char *rt_last_error(void) { return g.err; }
 
+static void release_parts()
+{
+    for (auto &pt : g.parts) {
+        if (pt.device < 0) continue;
+        (void)hipSetDevice(pt.device);
+        if (pt.stream) (void)hipStreamSynchronize(pt.stream);
+        if (pt.d_scene) (void)hipFree(pt.d_scene);
+        if (pt.d_part) (void)hipFree(pt.d_part);
+        if (pt.d_work) (void)hipFree(pt.d_work);
+        if (pt.d_pend_ws) (void)hipFree(pt.d_pend_ws);
+        if (pt.done) (void)hipEventDestroy(pt.done);
+        if (pt.frame_free) (void)hipEventDestroy(pt.frame_free);
+        if (pt.stream) (void)hipStreamDestroy(pt.stream);
+    }
+    g.parts.clear();
+    if (g.device >= 0) (void)hipSetDevice(g.device);
+}
+
 static void release_all()
 {
+    release_parts();
     if (g.d_scene) (void)hipFree(g.d_scene);
     if (g.d_out) (void)hipFree(g.d_out);
     if (g.d_events) (void)hipFree(g.d_events);
@@ -551,6 +584,20 @@ int rt_set_scene(const rt_object *objs, int n)
     g.layout = L;
     g.have_scene = true;
     g.scene_objs.assign(objs, objs + n);
+    // every device that renders a part holds its own copy of the scene
+    for (auto &pt : g.parts) {
+        HIP_TRY(hipSetDevice(pt.device));
+        if (bytes > pt.d_scene_cap) {
+            if (pt.d_scene) HIP_TRY(hipFree(pt.d_scene));
+            pt.d_scene = nullptr; pt.d_scene_cap = 0;
+            size_t cap = bytes < 4096 ? 4096 : bytes;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_scene), cap));
+            pt.d_scene_cap = cap;
+        }
+        HIP_TRY(hipStreamSynchronize(pt.stream));
+        HIP_TRY(hipMemcpy(pt.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
+    }
+    if (!g.parts.empty()) HIP_TRY(hipSetDevice(g.device));
     if (L.n1 > 0) return ensure_workspace();     // large scenes render as persistent waves
     return RT_OK;
 }
@@ -581,6 +628,8 @@ size_t rt_output_bytes(const rt_params *p)
     return (size_t)part_rows(p) * (size_t)p->width * bpp;
 }
 
+static int render_multi(const rt_params *p, void *d_frame, hipStream_t s);
+
 int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed)
 {
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
@@ -590,8 +639,12 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     size_t need = rt_output_bytes(p);
     if (!d_out && need) return fail(RT_E_ARG, "output pointer is null");
     if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
-    KParams kp = make_kparams(p);
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
+    if (!g.parts.empty()) {
+        if (timed) return fail(RT_E_ARG, "kernel timing is per device: not available in multi-device mode");
+        return render_multi(p, d_out, s);
+    }
+    KParams kp = make_kparams(p);
     LaunchInfo info{};
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
     // waits (on the GPU) for the previous one, whatever streams the two are on
@@ -652,6 +705,130 @@ int rt_render_device_noalloc(const rt_params *p, void *d_out, size_t out_bytes, 
     return RT_OK;
 }
 
+// Output rows of the packed rows of one part, in order: bands part, part + nparts, ... of
+// RT_BAND_ROWS rows each (the last band of the image may be shorter).
+int rt_part_row_map(int height, int part, int nparts, int32_t *rows, int capacity)
+{
+    if (height <= 0 || nparts < 1 || part < 0 || part >= nparts) return fail(RT_E_ARG, "bad part/nparts");
+    int bands = (height + RT_BAND_ROWS - 1) / RT_BAND_ROWS, k = 0;
+    for (int b = part; b < bands; b += nparts)
+        for (int r = b * RT_BAND_ROWS; r < (b + 1) * RT_BAND_ROWS && r < height; ++r) {
+            if (rows && k < capacity) rows[k] = r;
+            ++k;
+        }
+    return k;
+}
+
+// rt_init_multi mode: every part renders on its device; its bands go straight into the frame
+// `d_frame` on the first device (strided device-to-device copies over xGMI, no gather buffer and no
+// assemble pass); `s` (a stream of the first device) continues once all parts are in.
+static int render_multi(const rt_params *p, void *d_frame, hipStream_t s)
+{
+    const int np = (int)g.parts.size();
+    if (p->nparts != 1 || p->part != 0) return fail(RT_E_ARG, "in multi-device mode the library splits the frame itself: part/nparts must be 0/1");
+    const size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : (p->flags & RT_FLAG_OUT_RGB8) ? 3 : 4;
+    const size_t row_bytes = (size_t)p->width * bpp, band_bytes = row_bytes * RT_BAND_ROWS;
+    const int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+    const int tail_rows = p->height - (bands - 1) * RT_BAND_ROWS;          // rows of the last band (1..RT_BAND_ROWS)
+    // the frame must not be overwritten before earlier work on `s` that reads it has run
+    HIP_TRY(hipEventRecord(g.parts[0].frame_free, s));
+    for (int i = 0; i < np; ++i) {
+        State::Part &pt = g.parts[i];
+        rt_params q = *p;
+        q.part = i; q.nparts = np;
+        const size_t need = rt_output_bytes(&q);
+        HIP_TRY(hipSetDevice(pt.device));
+        if (need > pt.d_part_cap) {
+            if (pt.d_part) HIP_TRY(hipFree(pt.d_part));
+            pt.d_part = nullptr; pt.d_part_cap = 0;
+            HIP_TRY(hipMalloc(&pt.d_part, need ? need : 16));
+            pt.d_part_cap = need ? need : 16;
+        }
+        const int my_bands = (bands - i + np - 1) / np;
+        if (my_bands <= 0) { HIP_TRY(hipEventRecord(pt.done, pt.stream)); continue; }
+        KParams kp = make_kparams(&q);
+        kp.work_counter = pt.d_work;
+        kp.resident_workgroups = pt.resident_workgroups;
+        if (rt_uses_workspace(kp) && !pt.d_pend_ws) {
+            size_t ws = (size_t)pt.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_pend_ws), ws));
+        }
+        kp.pend_ws = pt.d_pend_ws;
+        HIP_TRY(hipStreamWaitEvent(pt.stream, g.parts[0].frame_free, 0));
+        LaunchInfo info{};
+        int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, &info)
+                                                 : rt_strict::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, &info);
+        if (lrc) return fail(RT_E_HIP, "kernel launch failed on device %d: %s", pt.device, hipGetErrorString((hipError_t)lrc));
+        // bands i, i + np, ...: contiguous in the part buffer, np bands apart in the frame
+        const bool owns_tail = (bands - 1) % np == i && tail_rows != RT_BAND_ROWS;
+        const int full = owns_tail ? my_bands - 1 : my_bands;
+        char *dst = static_cast<char *>(d_frame) + (size_t)i * band_bytes;
+        if (full > 0)
+            HIP_TRY(hipMemcpy2DAsync(dst, band_bytes * np, pt.d_part, band_bytes, band_bytes, full, hipMemcpyDeviceToDevice, pt.stream));
+        if (owns_tail)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)full * band_bytes * np, static_cast<char *>(pt.d_part) + (size_t)full * band_bytes,
+                                   row_bytes * tail_rows, hipMemcpyDeviceToDevice, pt.stream));
+        HIP_TRY(hipEventRecord(pt.done, pt.stream));
+        if (i == 0) { g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap; }
+    }
+    HIP_TRY(hipSetDevice(g.device));
+    for (int i = 0; i < np; ++i) HIP_TRY(hipStreamWaitEvent(s, g.parts[i].done, 0));
+    return RT_OK;
+}
+
+int rt_init_multi_devices(const int *devices, int n)
+{
+    if (g.inited) return fail(RT_E_STATE, "already initialised; call rt_shutdown first");
+    if (!devices || n < 1 || n > 64) return fail(RT_E_ARG, "bad device list");
+    int rc = rt_init(devices[0]);
+    if (rc) return rc;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    g.parts.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (devices[i] < 0 || devices[i] >= count) {
+            rc = fail(RT_E_ARG, "device %d out of range (0..%d)", devices[i], count - 1);
+            break;
+        }
+        State::Part &pt = g.parts[i];
+        pt.device = devices[i];
+        auto mk = [&]() -> int {
+            HIP_TRY(hipSetDevice(pt.device));
+            if (pt.device != g.device) {
+                // the part's stream writes into the frame on the first device
+                hipError_t e = hipDeviceEnablePeerAccess(g.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(RT_E_HIP, "device %d cannot access device %d: %s", pt.device, g.device, hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            HIP_TRY(hipStreamCreateWithFlags(&pt.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&pt.done, hipEventDisableTiming));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_work), RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int)));
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, pt.device));
+            pt.resident_workgroups = prop.multiProcessorCount * 4;
+            HIP_TRY(hipSetDevice(g.device));
+            HIP_TRY(hipEventCreateWithFlags(&pt.frame_free, hipEventDisableTiming));
+            return 0;
+        };
+        rc = mk();
+        if (rc) break;
+    }
+    if (rc) { char err[sizeof g.err]; std::memcpy(err, g.err, sizeof err); rt_shutdown(); std::memcpy(g.err, err, sizeof err); return rc; }
+    HIP_TRY(hipSetDevice(g.device));
+    return RT_OK;
+}
+
+int rt_init_multi(int n_devices)
+{
+    if (n_devices < 1 || n_devices > 64) return fail(RT_E_ARG, "n_devices must be 1..64");
+    int ids[64];
+    for (int i = 0; i < n_devices; ++i) ids[i] = i;
+    return rt_init_multi_devices(ids, n_devices);
+}
+
+int rt_device_count(void) { return g.inited ? (g.parts.empty() ? 1 : (int)g.parts.size()) : 0; }
+
 int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_t out_bytes)
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -664,7 +841,7 @@ int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_
     if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     rc = ensure_out(need);
     if (rc) return rc;
-    rc = rt_render_device(p, g.d_out, need, g.stream, 1);
+    rc = rt_render_device(p, g.d_out, need, g.stream, g.parts.empty() ? 1 : 0);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, g.d_out, need, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));

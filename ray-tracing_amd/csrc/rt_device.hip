@@ -762,15 +762,15 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    // the attribute is kept per device: set it again when this variant first runs on another one
-    static int attr_device = -1;
+    // the attribute is kept per device: set it when this variant first runs on a device
+    static unsigned long long attr_devices = 0ull;       // bit d: set on device d
     int cur_device = -1;
-    if (hipGetDevice(&cur_device) != hipSuccess) return (int)hipErrorInvalidDevice;
-    if (attr_device != cur_device) {
+    if (hipGetDevice(&cur_device) != hipSuccess || cur_device < 0 || cur_device > 63) return (int)hipErrorInvalidDevice;
+    if (!((attr_devices >> cur_device) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_device = cur_device;
+        attr_devices |= 1ull << cur_device;
     }
     int bands = (kp.h + 15) / 16;
     int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;
