@@ -181,18 +181,23 @@ class App:
                 pressed, events = (), ()
                 if script is not None and i < len(script):
                     pressed, events = script[i]
-                focused = True
-                if self.window is not None:
-                    events = list(events) + self.window.poll()
-                    pressed = set(pressed) | self.window.pressed_keys()
-                    focused = self.window.focused()
-                self.update_timing()
+                # the reference's iteration (main.py:174-178): update_timing, process_input, render,
+                # poll_events (whose callbacks change the state the NEXT frame sees); scripted
+                # events stand for what was polled at the end of the iteration before
                 for ev in events:
                     self.dispatch(ev)
+                self.update_timing()
+                focused = True
+                if self.window is not None:
+                    pressed = set(pressed) | self.window.pressed_keys()     # glfw.get_key inside process_input
+                    focused = self.window.focused()
                 self.process_input(pressed, focused)
                 self.render()
                 if png_pattern:
                     write_png(png_pattern % i, self.frame)
+                if self.window is not None:
+                    for ev in self.window.poll():
+                        self.dispatch(ev)
                 i += 1
         finally:
             self.cleanup()

@@ -92,31 +92,31 @@ class CameraController:
     first_mouse: bool = True
     mouse_captured: bool = True
 
-    def __post_init__(self):
-        self._eye = np.array(self.camera.eye, dtype=np.float32)
-
     def process_keys(self, pressed, delta_time: float, focused: bool = True) -> None:
         """pressed: any container of 'W','A','S','D','SPACE','LSHIFT'."""
         if not focused:
             return
         speed = CAMERA_SPEED * delta_time
+        # the camera's eye is the single state, as App.eye in the reference (main.py:103, :326-337):
+        # read it every frame, so a position set from outside is not overwritten
+        eye = np.array(self.camera.eye, dtype=np.float32)
         view = view_direction(self.camera.yaw, self.camera.pitch)
         up = np.asarray(self.camera.up, dtype=np.float32)
         forward = _normalize(np.array([view[0], 0, view[2]]))
         right = _normalize(np.cross(forward, up))
         if "W" in pressed:
-            self._eye += forward * speed
+            eye += forward * speed
         if "S" in pressed:
-            self._eye -= forward * speed
+            eye -= forward * speed
         if "A" in pressed:
-            self._eye -= right * speed
+            eye -= right * speed
         if "D" in pressed:
-            self._eye += right * speed
+            eye += right * speed
         if "SPACE" in pressed:
-            self._eye += up * speed
+            eye += up * speed
         if "LSHIFT" in pressed:
-            self._eye -= up * speed
-        self.camera.eye = tuple(float(v) for v in self._eye)
+            eye -= up * speed
+        self.camera.eye = tuple(float(v) for v in eye)
 
     def capture_mouse(self, should_capture: bool) -> None:
         self.mouse_captured = should_capture

@@ -122,7 +122,8 @@ class BandPipeline:
 
     @property
     def image(self):
-        """The most recently completed frame (rank 0; None elsewhere)."""
+        """The buffer of the most recently ENQUEUED frame (rank 0; None elsewhere): its contents are
+        valid once flush() has been called and the current stream has been synchronised."""
         return self.images[self.last_image] if self.images is not None else None
 
     def use_stream(self, k):
