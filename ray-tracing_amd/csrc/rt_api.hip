@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -153,6 +154,33 @@ int part_rows(const rt_params *p)
     return rows;
 }
 
+// The primary ray's uv = (2 (x + 0.5) - w, 2 (y + 0.5) - h) / h (fragment_shader.glsl:650-653) has a
+// divisor that is the same for the whole frame.  q = n * RN(1/h), corrected once by the exact
+// remainder, is the correctly rounded n / h for almost all operands; this runs that sequence (the
+// kernel's div_by_reciprocal, same operations in binary32 with fused multiply-adds) over every
+// numerator the frame's pixel centres produce and says whether all of them came out equal to n / h.
+// The kernel takes the short sequence only then.  Checked once per frame size.
+bool uv_quotients_by_reciprocal(int w, int h)
+{
+    static std::mutex mu;
+    static int cw = 0, ch = 0;
+    static bool cok = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (w == cw && h == ch) return cok;
+    const float fw = (float)w, fh = (float)h, rd = 1.0f / fh;
+    bool ok = true;
+    auto same = [&](float n) {
+        const float q = n * rd;
+        const float r = std::fmaf(-fh, q, n);
+        const float v = std::fmaf(r, rd, q), want = n / fh;
+        return std::memcmp(&v, &want, 4) == 0;
+    };
+    for (int x = 0; x < w && ok; ++x) ok = same(((float)x + 0.5f) * 2.0f - fw);
+    for (int y = 0; y < h && ok; ++y) ok = same(((float)y + 0.5f) * 2.0f - fh);
+    cw = w; ch = h; cok = ok;
+    return ok;
+}
+
 KParams make_kparams(const rt_params *p)
 {
     KParams k{};
@@ -167,6 +195,8 @@ KParams make_kparams(const rt_params *p)
     k.focal = p->focal_length;
     for (int i = 0; i < 3; ++i) k.light[i] = p->light_pos[i];
     k.res_w = (float)p->width; k.res_h = (float)p->height;
+    k.inv_res_h = 1.0f / k.res_h;
+    k.uv_by_reciprocal = uv_quotients_by_reciprocal(p->width, p->height) ? 1 : 0;
     k.w = p->width; k.h = p->height;
     k.max_depth = p->max_depth; k.stack_size = p->stack_size; k.hops = p->shadow_hops; k.spp = p->spp_grid;
     k.bottom_up = (p->flags & RT_FLAG_BOTTOM_UP) ? 1 : 0;

@@ -220,8 +220,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // main() (:650-668): pixel centre + stratified offset
         float fx = (float)px + 0.5f, fy = (float)gy + 0.5f;
         if (MULTI) { fx = fx + kp.sample_off[si]; fy = fy + kp.sample_off[sj]; }
-        float uvx = rt_div(fx * 2.0f - kp.res_w, kp.res_h);
-        float uvy = rt_div(fy * 2.0f - kp.res_h, kp.res_h);
+        const float nx = fx * 2.0f - kp.res_w, ny = fy * 2.0f - kp.res_h;
+        float uvx, uvy;
+        if (!MULTI && kp.uv_by_reciprocal) {
+            // pixel centres only: the host has run this sequence on every numerator of the frame size
+            uvx = div_by_reciprocal(nx, kp.res_h, kp.inv_res_h);
+            uvy = div_by_reciprocal(ny, kp.res_h, kp.inv_res_h);
+        } else {
+            uvx = rt_div(nx, kp.res_h);
+            uvy = rt_div(ny, kp.res_h);
+        }
         float rx = (uvx * kp.right[0] + uvy * kp.up[0]) + kp.focal * kp.fwd[0];
         float ry = (uvx * kp.right[1] + uvy * kp.up[1]) + kp.focal * kp.fwd[1];
         float rz = (uvx * kp.right[2] + uvy * kp.up[2]) + kp.focal * kp.fwd[2];
@@ -264,9 +272,12 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         if (kp.out_mode == 1) {
             reinterpret_cast<float4 *>(out)[o] = make_float4(cr, cg, cb, 1.0f);
         } else {
+            // clamp to [0, 1] with NaN -> 0 (v_med3_f32 returns the minimum of the three when one is
+            // NaN), scale, and round to nearest even by adding 2^23: the sum's low mantissa byte is
+            // RN(s * 255)
             auto u8 = [](float c) -> uint32_t {
-                float s = !(c > 0.0f) ? 0.0f : (c >= 1.0f ? 1.0f : c);
-                return (uint32_t)__builtin_rintf(s * 255.0f);
+                const float s = __builtin_amdgcn_fmed3f(c, 0.0f, 1.0f);
+                return __float_as_uint(s * 255.0f + 8388608.0f) & 0xffu;
             };
             const uint32_t r8 = u8(cr), g8 = u8(cg), b8 = u8(cb);
             if (kp.out_mode == 2) {

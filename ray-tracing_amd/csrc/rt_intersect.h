@@ -38,6 +38,7 @@ template <> struct Counters<true> {
 // ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
 #define Q_EPS 1e-7f
 
+// [census: root_offer @ QUAD_ROOTS*0.2]   (ten inlined copies; a quadratic with real roots runs two of them)
 struct RootMin {
     float t; bool found;
     DEV void offer(float r) { if (r > 0.001f && r < t) { t = r; found = true; } }

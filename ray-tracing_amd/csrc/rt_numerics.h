@@ -15,6 +15,7 @@ DEV float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV float rt_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 DEV float rt_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
 template <int C> DEV float rt_div_const(float x) { return x * (1.0f / (float)C); }
+DEV float div_by_reciprocal(float x, float d, float rd) { return x * rd; }
 #else
 // strict flavour: correctly rounded, as the reference's CPU GL computes them.
 //
@@ -73,6 +74,16 @@ template <int C> DEV float div_const_core(float x)
     float q = x * rc;
     float r = __builtin_fmaf(-c, q, x);
     return __builtin_fmaf(r, rc, q);
+}
+// x / d given rd = RN(1/d): the same three instructions with a divisor known at run time.  Whether
+// the result is the correctly rounded quotient depends on (x, d); callers use it only for operand
+// sets the host has checked one by one with this very sequence (uv_quotients_by_reciprocal in
+// rt_api.hip).
+DEV float div_by_reciprocal(float x, float d, float rd)
+{
+    float q = x * rd;
+    float r = __builtin_fmaf(-d, q, x);
+    return __builtin_fmaf(r, rd, q);
 }
 DEV bool div_const_in_core_range(float x) { return ((f_bits(x) & 0x7fffffffu) - 0x0f800000u) < 0x60000000u; }
 template <int C> DEV float rt_div_const(float x)

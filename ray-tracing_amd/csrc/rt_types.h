@@ -75,6 +75,9 @@ struct KParams {
     float focal;
     float light[3];
     float res_w, res_h;
+    float inv_res_h;        // RN(1 / res_h)
+    int uv_by_reciprocal;   // the host has checked, for every pixel centre of this frame size, that the short
+                            // reciprocal sequence returns the correctly rounded quotient by res_h
     int w, h;
     int max_depth, stack_size, hops, spp;
     int bottom_up;          // output row order
