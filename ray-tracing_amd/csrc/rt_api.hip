@@ -181,6 +181,7 @@ bool uv_quotients_by_reciprocal(int w, int h)
     return ok;
 }
 
+int coop_rays_for(int n);
 KParams make_kparams(const rt_params *p)
 {
     KParams k{};
@@ -224,6 +225,26 @@ KParams make_kparams(const rt_params *p)
         k.sample_off[i] = i < p->spp_grid ? (float)(((double)i + 0.5) / (double)p->spp_grid - 0.5) : 0.0f;
     k.scene = g.layout;
     k.use_hierarchy = (g.layout.n1 > 0 && !(p->flags & RT_FLAG_NO_ACCEL)) ? 1 : 0;
+    // Deep path trees (the frame time is then set by the waves that hold the deepest pixels, not by
+    // throughput): hand out the pixels of 64 different tiles to a wave, and let a wave that is down to
+    // a few rays trace them one at a time with all lanes.  Shallow frames keep whole 8x8 tiles per
+    // wave: there the coherence of neighbouring primary rays is worth more (64 tori 4K depth 8:
+    // 2.2 ms with tiles, 3.3 ms spread; 256 spheres 1080p depth 16: 319 -> 172 ms spread).
+    const bool deep = p->max_depth >= 12 && std::min(p->stack_size, p->max_depth - 1) >= 8 && k.use_hierarchy;
+    k.spread_shift = deep ? 0 : 6;
+    k.coop_rays = deep ? coop_rays_for(g.layout.n) : 0;
+#ifdef RT_DEV_SWITCHES
+    if (const char *e = getenv("RT_SPREAD_SHIFT")) k.spread_shift = atoi(e);
+    if (const char *e = getenv("RT_COOP_RAYS")) k.coop_rays = atoi(e);
+#endif
+    k.spread_stride = 0;
+    if (k.spread_shift < 0 || k.spread_shift > 6) k.spread_shift = 6;
+    if (k.spread_shift < 6) {
+        const int ntiles = ((p->width + 7) / 8) * k.my_bands * 2;
+        const int groups = 64 >> k.spread_shift;
+        k.spread_stride = ntiles / groups;      // (groups - 1) * stride < ntiles: one conditional subtraction in the kernel
+        if (k.spread_stride < 1) k.spread_shift = 6;
+    }
     return k;
 }
 
@@ -241,6 +262,16 @@ int hierarchy_min_objects()
 #else
     return 40;
 #endif
+}
+
+// Rays a wave of the persistent hierarchy kernels may have left when it starts tracing them one at a
+// time with all 64 lanes (trace_cooperative: n / 64 rounds of object tests per ray, against one
+// hierarchy walk for all of the wave's rays together; measured best at 6 for 256 and for 1024 objects).
+int coop_rays_for(int n)
+{
+    static_assert(RT_MAX_OBJECTS <= 1024, "the threshold was measured for up to 1024 objects (16 rounds per ray)");
+    (void)n;
+    return 6;
 }
 
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes

@@ -89,6 +89,9 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // magnitude between neighbouring pixels at depth 16, so without this most lanes of a wave
 // wait for its longest pixel.  With kp.whole_tiles the pixels are handed out only when the
 // whole wave is idle: tile after tile with the lanes in lock-step (small scenes).
+// DEEP (persistent hierarchy kernels): the code for frames of deep path trees -- a wave's pixels
+// come from 64 different tiles (kp.spread_shift / kp.spread_stride), and a wave with at most
+// kp.coop_rays rays left traces them one at a time with all lanes (trace_cooperative).
 // PEND: where the pending-ray slots live: PEND_REG registers (CAP of them, compare/select
 // addressing), PEND_LDS ([slot][field][thread] after the scene), PEND_GLOBAL (same layout in a
 // per-workgroup slice of a global workspace; persistent-wave kernels only, whose grid is
@@ -105,7 +108,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_WG_ONE 64
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false>
 __global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
@@ -346,9 +349,18 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 }
                 if (!active) {
                     int idx = pool_next + my;
-                    const int tile = idx < 64 ? pool_tile : new_tile;
+                    int tile = idx < 64 ? pool_tile : new_tile;
                     idx &= 63;
                     if (tile >= 0) {
+                        // Spread: queue entry `tile` stands for pixel groups (1 << spread_shift lanes each) of
+                        // 64 >> spread_shift different tiles, kp.spread_stride apart in the tile sequence,
+                        // so that a cluster of deep pixels ends up a few lanes each in many waves.  Slot idx
+                        // of entry v is slot idx of tile v + (idx >> shift) * stride (mod ntiles): for
+                        // every idx a rotation of the tile sequence, hence every pixel exactly once.
+                        if (DEEP && kp.spread_shift < 6) {
+                            tile += (idx >> kp.spread_shift) * kp.spread_stride;
+                            tile = tile >= ntiles ? tile - ntiles : tile;
+                        }
                         // the queue walks the 8x8 tiles down the columns, the columns from the
                         // centre outwards (as the one-pixel-per-lane kernels dispatch theirs)
                         const int col = tile / tile_rows8, ty = tile - col * tile_rows8;
@@ -379,13 +391,26 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 #ifdef RT_DEV_SWITCHES
         dev_trips++;
 #endif
+        // A wave that is down to its last few rays (deep pixels, nothing left to refill with) puts
+        // all of its lanes on one ray at a time instead of walking the hierarchy with most lanes idle.
+        constexpr bool COOP = DEEP;
+        float t_coop = 0.0f; int id_coop = -1;
+        bool coop = false;
+        if (COOP) {
+            const int nrays = __popcll(__ballot(active));
+            if (nrays <= kp.coop_rays) {
+                trace_cooperative<DEBUG>(sc, L, kp.polish, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
+                coop = true;
+            }
+        }
         do {
         if (REFILL && !active) break;
         if (SYNC && (!active || parked)) break;
         // [census: trace_call @ ITER]
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
-        if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
+        if (COOP && coop) { t = t_coop; id = id_coop; }
+        else if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
         else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
 
         bool spawn = false;     // this lane finished shading a hit: spawn children
@@ -757,7 +782,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 __global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
@@ -767,7 +792,8 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
                   "the global pending-ray workspace is sliced by persistent workgroup");
     if ((PEND == PEND_GLOBAL || PEND == PEND_HYBRID) && !kp.pend_ws) return (int)hipErrorInvalidValue;
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
-    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL>;
+    static_assert(!DEEP || (HIER && REFILL && !DEBUG), "the deep-frame code belongs to the persistent hierarchy kernels");
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
@@ -820,12 +846,16 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     const RtVariantFamily family = rt_variant_family(kp);
     const bool no_ldsp = dev_no_ldsp;
     const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
+    // deep frames (the host's choice, see make_kparams): pixels spread over waves + cooperative trace
+    const bool deep = kp.coop_rays > 0 || kp.spread_shift < 6;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
            : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
 #define RT_LAUNCH_HIER(CAP_, PEND_)                                                                         \
-    (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
-           : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info))
+    (deep ? (multi ? launch_variant<CAP_, false, PEND_, true, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)  \
+                   : launch_variant<CAP_, false, PEND_, false, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)) \
+          : (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)        \
+                   : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)))
     // Large scenes run as persistent waves with pixel refill (measured 1.1-2.4x there: 64 tori
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
     // 2250 -> 928 ms).  The 5-object scene keeps one pixel per lane: there the lanes' loss of

@@ -256,33 +256,14 @@ DEV void object_centre(const float *lds, int id, float &cx, float &cy, float &cz
     cx = p[0]; cy = p[2]; cz = p[4];
 }
 
-// Exact test of one object whose bounding test did not reject it (:405-425).
+// The exact intersection of one object (:74-92 sphere, :250-375 torus) given the terms of its
+// bounding test; kd = the object's kind word (negative: sphere, else the index of its torus frame).
 template <bool DEBUG>
-DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int i, float a,
-                        float ocx, float ocy, float ocz, float b, float c, float disc,
-                        float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
+DEV void candidate_exact(const float *lds, const SceneLayout &L, int polish, int kd, float a,
+                         float ocx, float ocy, float ocz, float b, float c,
+                         float dx, float dy, float dz, float &t, bool &hit, const Counters<DEBUG> &cnt)
 {
-    // [census: candidate @ CAND]
-    CNT(EV_BOUND_TBOUND);
-    WCNT(WP_CAND); LCNT(WP_CAND_LANES);
-    const int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
-    // A sphere behind the ray (centre behind the origin, origin outside: the sphere a reflected or
-    // shadow ray has just left, most of the time) cannot be hit: in intersect_sphere below the
-    // discriminant is RN((2b)^2) minus a non-negative product, so its root is <= 2b and both
-    // quotients are <= +0, which fails t > 0.001.  An object that is not hit changes nothing in
-    // the reference's loop, so the instrumented flavour alone goes through the motions (its
-    // counters are the reference's work).  b < 1e15 keeps (2b)^2 finite.
-    if (!DEBUG && kd < 0 && b > 0.0f && b < 1e15f && c >= 0.0f) return;
-    // t_bound > closest.t can only hold once something has been hit: while closest.t is
-    // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
-    if (bt < 1e30f) {
-        // [census: t_bound @ TBOUND]
-        WCNT(WP_TBOUND);
-        float t_bound = -b - rt_sqrt(disc);
-        if (t_bound > bt) return;
-    }
     // [census: candidate_kind @ CAND]
-    float t; bool hit;
     if (kd < 0) {
         // intersect_sphere (:74-92); c is the same dot(oc,oc) - r*r
         // [census: sphere @ SPHERE]
@@ -311,6 +292,36 @@ DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int 
         hit = torus_nearest<DEBUG>(f, ocx, ocy, ocz, dx, dy, dz, polish, t, cnt);
         if (hit) CNT(EV_TORUS_HIT);
     }
+}
+
+// Exact test of one object whose bounding test did not reject it (:405-425).
+template <bool DEBUG>
+DEV void test_candidate(const float *lds, const SceneLayout &L, int polish, int i, float a,
+                        float ocx, float ocy, float ocz, float b, float c, float disc,
+                        float dx, float dy, float dz, float &bt, int &bid, const Counters<DEBUG> &cnt)
+{
+    // [census: candidate @ CAND]
+    CNT(EV_BOUND_TBOUND);
+    WCNT(WP_CAND); LCNT(WP_CAND_LANES);
+    const int kd = reinterpret_cast<const int *>(lds + L.off_kind)[i];
+    // A sphere behind the ray (centre behind the origin, origin outside: the sphere a reflected or
+    // shadow ray has just left, most of the time) cannot be hit: in intersect_sphere below the
+    // discriminant is RN((2b)^2) minus a non-negative product, so its root is <= 2b and both
+    // quotients are <= +0, which fails t > 0.001.  An object that is not hit changes nothing in
+    // the reference's loop, so the instrumented flavour alone goes through the motions (its
+    // counters are the reference's work).  b < 1e15 keeps (2b)^2 finite.
+    if (!DEBUG && kd < 0 && b > 0.0f && b < 1e15f && c >= 0.0f) return;
+    // t_bound > closest.t can only hold once something has been hit: while closest.t is
+    // still 1e30 the comparison is false for every finite ray, so the sqrt is skipped.
+    if (bt < 1e30f) {
+        // [census: t_bound @ TBOUND]
+        WCNT(WP_TBOUND);
+        float t_bound = -b - rt_sqrt(disc);
+        if (t_bound > bt) return;
+    }
+    // [census: candidate_kind @ CAND]
+    float t; bool hit;
+    candidate_exact<DEBUG>(lds, L, polish, kd, a, ocx, ocy, ocz, b, c, dx, dy, dz, t, hit, cnt);
     // [census: candidate_end @ CAND]
     if (hit && t < bt) { bt = t; bid = i; }
 }
@@ -609,6 +620,74 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     }
     offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
     best_t = bt; best_id = bid;
+}
+
+// ------------------------------------------------------------------ one ray at a time, the whole wave on it
+//
+// For waves that have only a few rays left (the deepest pixels of a frame, after the tile queue has
+// run dry): the rays are taken one after the other, and for each of them lane l runs the
+// reference's bounding test (:399-402) and, where it passes, the exact intersection on objects
+// l, l + 64, ... -- the same binary32 operations on the same operands as the per-lane loop, so each
+// object's (t, hit) and t_bound are the same bits.  What the reference's loop does with them depends
+// on the order (the t_bound > closest.t skip, "first index wins"), so the hits are then replayed in
+// ascending object index on wave-uniform values.  Objects that are not hit change nothing in the
+// reference's loop and are left out of the replay; so are the spheres behind the ray (see
+// test_candidate).  No enclosing spheres are involved.  `mine` marks the lanes that hold a ray;
+// all 64 lanes must enter.
+DEV float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <bool DEBUG>
+DEV void trace_cooperative(const float *sc, const SceneLayout &L, int polish, bool mine,
+                           float ox, float oy, float oz, float dx, float dy, float dz,
+                           float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = L.n;
+    const int *kind = reinterpret_cast<const int *>(sc + L.off_kind);
+    unsigned long long rays = __ballot(mine);
+    float my_t = 1e30f;
+    int my_id = -1;
+    while (rays) {
+        const int r = __builtin_ctzll(rays);
+        rays &= rays - 1;
+        const float rox = lane_value(ox, r), roy = lane_value(oy, r), roz = lane_value(oz, r);
+        const float rdx = lane_value(dx, r), rdy = lane_value(dy, r), rdz = lane_value(dz, r);
+        const float a = dot3(rdx, rdy, rdz, rdx, rdy, rdz);
+        float bt = 1e30f;
+        int bid = -1;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const int ic = i < n ? i : n - 1;
+            const float *rec = sc + 8 * (ic >> 1) + (ic & 1);
+            const float ocx = rox - rec[0], ocy = roy - rec[2], ocz = roz - rec[4];
+            const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+            const float c = oc2 - rec[6];
+            const float b = (ocz * rdz + ocy * rdy) + ocx * rdx;
+            const float disc = b * b - c;
+            float t = 0.0f, tb = 0.0f;
+            bool hit = false;
+            if (i < n && !(disc < 0.0f)) {
+                const int kd = kind[ic];
+                if (!(kd < 0 && b > 0.0f && b < 1e15f && c >= 0.0f)) {
+                    tb = -b - rt_sqrt(disc);
+                    candidate_exact<DEBUG>(sc, L, polish, kd, a, ocx, ocy, ocz, b, c, rdx, rdy, rdz, t, hit, cnt);
+                }
+            }
+            unsigned long long hits = __ballot(hit);
+            while (hits) {
+                const int k = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                const float tbk = lane_value(tb, k), tk = lane_value(t, k);
+                if (bt < 1e30f && tbk > bt) continue;      // the reference skips this object (:412-415)
+                if (tk < bt) { bt = tk; bid = base + k; }
+            }
+        }
+        if (lane == r) { my_t = bt; my_id = bid; }
+    }
+    if (mine) {
+        offer_plane<DEBUG>(oy, dy, n, my_t, my_id, cnt);
+        best_t = my_t; best_id = my_id;
+    }
 }
 
 }  // namespace RT_NS

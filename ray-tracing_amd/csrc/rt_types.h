@@ -99,6 +99,10 @@ struct KParams {
     float light_off[RT_MAX_LIGHT_GRID];   // ((i + 0.5)/G - 0.5) * light_size for i < G
     SceneLayout scene;
     int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
+    int spread_shift;       // persistent kernels: log2 of the lanes that take neighbouring pixels (6: a wave's 64 pixels
+    int spread_stride;      // are one 8x8 tile); smaller: groups from tiles spread_stride apart in the queue order
+    int coop_rays;          // persistent hierarchy kernels: a wave with at most this many rays left traces them
+                            // one at a time with all lanes (0: never)
 #ifdef RT_DEV_SWITCHES
     unsigned long long *wave_log;   // development builds: per persistent wave {start, end (100 MHz ticks), loop trips, pixels}
 #endif
