@@ -49,7 +49,7 @@ struct State {
     hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
     bool ws_busy = false;
 #ifdef RT_DEV_SWITCHES
-    unsigned long long *d_wave_log = nullptr;   // 4 words per resident wave (development builds)
+    unsigned long long *d_wave_log = nullptr;   // RT_WAVE_LOG_WORDS words per resident wave (development builds)
 #endif
     std::vector<rt_object> scene_objs;      // the objects of the staged scene (rt_set_scene skips an unchanged scene)
     // rt_init_multi: one context per part of the frame.  Part i is rendered on parts[i].device into
@@ -531,7 +531,7 @@ static int init_device(int device)
         g.resident_workgroups = prop.multiProcessorCount * 4;
     }
 #ifdef RT_DEV_SWITCHES
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_wave_log), (size_t)g.resident_workgroups * 4 * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_wave_log), (size_t)g.resident_workgroups * 4 * RT_WAVE_LOG_WORDS * sizeof(unsigned long long)));
     rt_strict::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
     rt_fast::set_dev_switch(0, getenv("RT_NO_LDSP") != nullptr);
 #endif
@@ -1023,12 +1023,12 @@ int rt_dev_wave_log(uint64_t *out, int max_waves)
     if (!g.inited || !out) return fail(RT_E_ARG, "bad wave log arguments");
     int n = g.resident_workgroups * 4 < max_waves ? g.resident_workgroups * 4 : max_waves;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, g.d_wave_log, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, g.d_wave_log, (size_t)n * RT_WAVE_LOG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return n;
 }
 int rt_dev_wave_log_clear(void)
 {
-    HIP_TRY(hipMemset(g.d_wave_log, 0, (size_t)g.resident_workgroups * 4 * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(g.d_wave_log, 0, (size_t)g.resident_workgroups * 4 * RT_WAVE_LOG_WORDS * sizeof(unsigned long long)));
     return RT_OK;
 }
 void rt_dev_switch(int which, int value)

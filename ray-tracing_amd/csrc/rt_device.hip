@@ -104,6 +104,11 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 // per workgroup: a workgroup keeps its LDS and its wave slots until its last wave ends, and ray
 // trees differ a lot between neighbouring tiles, so the three waves that finish first would leave
 // their SIMD slots empty until the fourth does.
+// 1: the hierarchy kernels pool the member tests and exact intersections of a wave's 64 rays
+// (trace_hierarchy_flat); 0: every lane walks its own lists (trace_hierarchy)
+#ifndef RT_FLAT
+#define RT_FLAT 1
+#endif
 #ifndef RT_WG_ONE
 #define RT_WG_ONE 64
 #endif
@@ -202,6 +207,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     (void)LDSP;
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
     unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3)) + threadIdx.x;
+    // pooled hierarchy trace: RT_FLAT_DWORDS of LDS per wave, in the same region
+    float *flat_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) + (threadIdx.x >> 6) * RT_FLAT_DWORDS;
+    (void)flat_lds;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit
     float hx = 0, hy = 0, hz = 0;            // hit position
@@ -394,8 +402,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // A wave that is down to its last few rays (deep pixels, nothing left to refill with) puts
         // all of its lanes on one ray at a time instead of walking the hierarchy with most lanes idle.
         constexpr bool COOP = DEEP;
+        constexpr bool FLAT = HIER && REFILL && !DEBUG && RT_FLAT;
         float t_coop = 0.0f; int id_coop = -1;
-        bool coop = false;
+        bool coop = false;      // this trip's trace is done here, by the whole wave (wave-uniform)
         if (COOP) {
             const int nrays = __popcll(__ballot(active));
             if (nrays <= kp.coop_rays) {
@@ -403,13 +412,17 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 coop = true;
             }
         }
+        if (FLAT && !coop) {
+            trace_hierarchy_flat<DEBUG>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
+            coop = true;
+        }
         do {
         if (REFILL && !active) break;
         if (SYNC && (!active || parked)) break;
         // [census: trace_call @ ITER]
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
-        if (COOP && coop) { t = t_coop; id = id_coop; }
+        if ((COOP || FLAT) && coop) { t = t_coop; id = id_coop; }
         else if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
         else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
 
@@ -760,8 +773,16 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         unsigned long long px_done = dev_pixels;
         for (int o = 32; o > 0; o >>= 1) px_done += __shfl_xor(px_done, o);
         if (lane == 0) {
-            unsigned long long *w = kp.wave_log + ((size_t)blockIdx.x * 4 + wave) * 4;
+            unsigned long long *w = kp.wave_log + ((size_t)blockIdx.x * 4 + wave) * RT_WAVE_LOG_WORDS;
             w[0] = dev_t0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = dev_trips; w[3] = px_done;
+        }
+        if constexpr (!DEBUG) {
+            unsigned long long *w = kp.wave_log + ((size_t)blockIdx.x * 4 + wave) * RT_WAVE_LOG_WORDS;
+            for (int k = 0; k < HS_COUNT; ++k) {
+                unsigned long long a = cnt.hs_wave[k], b = cnt.hs_lane[k];
+                for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if (lane == 0) { w[4 + k] = a; w[4 + HS_COUNT + k] = b; }
+            }
         }
     }
 #endif
@@ -797,7 +818,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
-    if (HIER) lds = ((lds + 15) & ~(size_t)15) + (size_t)RT_QUEUE * 256 * 2;
+    if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS * 4 : (size_t)RT_QUEUE * 256 * 2);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // the attribute is kept per device: set it when this variant first runs on a device
     static unsigned long long attr_devices = 0ull;       // bit d: set on device d

@@ -9,12 +9,24 @@ namespace RT_NS {
 // Two uses of the same LDS counter array in the instrumented flavour: event counts (one per
 // lane and event, the FLOP accounting), or -- wave_mode -- a profile of the code blocks a wave
 // executes (WCNT: once per wave that enters the block with any lane; LCNT: lanes in it).
+enum { HS_TOP, HS_LEAF, HS_CAND, HS_SCAN, HS_COOP_RAY, HS_COOP_ROUND, HS_COUNT };
 template <bool DEBUG> struct Counters {
     unsigned int *lds_ev;
     DEV void add(int) const {}
     DEV void wave(int) const {}
     DEV void lanes(int) const {}
     DEV bool counting_events() const { return false; }
+#ifdef RT_DEV_SWITCHES
+    // development builds: loop iterations of the hierarchy walk, per wave (the lowest active lane counts) and per lane
+    mutable unsigned int hs_wave[HS_COUNT] = {}, hs_lane[HS_COUNT] = {};
+    DEV void hstat(int k) const
+    {
+        hs_lane[k]++;
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) hs_wave[k]++;
+    }
+#else
+    DEV void hstat(int) const {}
+#endif
 };
 template <> struct Counters<true> {
     unsigned int *lds_ev;
@@ -30,10 +42,12 @@ template <> struct Counters<true> {
     DEV void lanes(int slot) const { if (wave_mode) atomicAdd(&lds_ev[slot], 1u); }
     // the event counts are the reference's work, object by object: no shortcuts while counting
     DEV bool counting_events() const { return !wave_mode; }
+    DEV void hstat(int) const {}
 };
 #define CNT(ev) cnt.add(ev)
 #define WCNT(slot) cnt.wave(slot)
 #define LCNT(slot) cnt.lanes(slot)
+#define HSTAT(k) cnt.hstat(k)
 
 // ------------------------------------------------------------------ torus (fragment_shader.glsl:250-375)
 #define Q_EPS 1e-7f
@@ -497,13 +511,14 @@ DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v
     keep1 = !(s.y < 0.0f) && !behind1;
 }
 
+// Step 1 down to the leaf level: bit masks of the leaf nodes this lane's ray keeps (0..63 / 64..127).
 template <bool DEBUG>
-DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L, int polish, unsigned short *queue,
-                         float ox, float oy, float oz, float dx, float dy, float dz,
-                         float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+DEV void hierarchy_kept_leaves(const float *hl, const SceneLayout &L,
+                               float ox, float oy, float oz, float dx, float dy, float dz,
+                               unsigned long long &leaf_lo_out, unsigned long long &leaf_hi_out, const Counters<DEBUG> &cnt)
 {
     const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
-    const int n = L.n, n1 = L.n1, n2 = L.n2;
+    const int n1 = L.n1, n2 = L.n2;
     const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
     const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
     // growth and slack of the node test, once per ray: every object and node lies inside the
@@ -520,14 +535,11 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     // hl = the hierarchy sections in LDS, starting at the top nodes
     const float4 *top = reinterpret_cast<const float4 *>(hl);
     const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
-    const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
-    const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
 
     // ---- step 1: collect the objects whose bounding test passes.
     // The top nodes are tested by all lanes together; below them every lane walks its own
     // list of kept nodes (bit masks), so a wave of incoherent rays pays for the longest list
     // of any lane, not for the union of all lists.
-    int count = 0;
     unsigned int top_mask = 0;
     for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
         bool k0, k1;
@@ -538,6 +550,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     unsigned long long leaf_lo = 0, leaf_hi = 0;        // kept leaf nodes 0..63 / 64..127
     const int last_leaf_pair = (n1 - 1) >> 1;
     while (top_mask) {
+        HSTAT(HS_TOP);
         const int tn = __builtin_ctz(top_mask);
         top_mask &= top_mask - 1;
         const int first = tn * RT_FAN;                       // first leaf node of this top node
@@ -555,7 +568,25 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
         const unsigned long long placed = (unsigned long long)bits << (first & 63);
         if (first < 64) leaf_lo |= placed; else leaf_hi |= placed;
     }
+    leaf_lo_out = leaf_lo; leaf_hi_out = leaf_hi;
+}
+
+template <bool DEBUG>
+DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L, int polish, unsigned short *queue,
+                         float ox, float oy, float oz, float dx, float dy, float dz,
+                         float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+{
+    const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
+    const int n = L.n;
+    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+    const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
+    const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
+    unsigned long long leaf_lo, leaf_hi;
+    hierarchy_kept_leaves<DEBUG>(hl, L, ox, oy, oz, dx, dy, dz, leaf_lo, leaf_hi, cnt);
+    int count = 0;
     while (leaf_lo | leaf_hi) {
+        HSTAT(HS_LEAF);
         int leaf;
         if (leaf_lo) { leaf = __builtin_ctzll(leaf_lo); leaf_lo &= leaf_lo - 1; }
         else { leaf = 64 + __builtin_ctzll(leaf_hi); leaf_hi &= leaf_hi - 1; }
@@ -599,6 +630,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
         if (!walk_all) {
             int mnext = 0x7fffffff;
             for (int q = 0; q < count; ++q) {
+                HSTAT(HS_SCAN);
                 int v = queue[q * 256];
                 mnext = (v > last && v < mnext) ? v : mnext;
             }
@@ -609,6 +641,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             if (i >= n) break;
         }
         last = i;
+        HSTAT(HS_CAND);
         const float *rec = sc + 8 * (i >> 1) + (i & 1);
         float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
         float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
@@ -620,6 +653,197 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     }
     offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
     best_t = bt; best_id = bid;
+}
+
+// ------------------------------------------------------------------ the same trace, the wave's work pooled
+//
+// trace_hierarchy above lets every lane walk its own lists, so the wave issues as many member tests
+// and exact intersections as its *longest* list has entries (measured on 256 spheres at depth 16:
+// 7.7 leaf iterations per trace with 25 lanes in them, 4.2 candidate iterations with 16).  Here the
+// lists of all 64 rays are pooled in LDS and dealt out evenly:
+//   1. every lane finds the leaf nodes its ray keeps (hierarchy_kept_leaves, as before) and writes
+//      them as (ray, leaf) items; lane j of a round takes item j, reads that ray from an LDS table
+//      and runs the reference's bounding test (:399-402) on the leaf's members;
+//   2. objects that pass (minus the spheres behind the ray, see trace_hierarchy) become
+//      (ray, object) items, dealt out the same way for the exact intersection (candidate_exact: the
+//      same binary32 operations on the same operands as in the per-lane form);
+//   3. per ray, LDS atomics keep the two smallest (t, object index) keys over its hits with
+//      t < 1e30 (t > 0.001 is positive, so the bit pattern orders like the number; equal t orders
+//      by index).
+// What the reference's loop (:386-426) makes of the hits: it visits them in ascending index, skips
+// object j when t_bound(j) > closest.t, and takes j when t(j) < closest.t.  Let m be the smallest
+// key.  Hits visited before m have t > t(m), hits after it t >= t(m): if m is not skipped it is
+// taken and never replaced.  m is skipped only if a hit taken before it has t < t_bound(m), so if no
+// other hit at all has t < t_bound(m) -- the second smallest key decides that -- the result is m.
+// Otherwise (two hits within rounding of each other, or a torus root that geometry rules out) the
+// lane runs the reference's loop over all objects.  All 64 lanes must enter; `mine` marks the
+// lanes that hold a ray.  wl = this wave's RT_FLAT_DWORDS dwords of LDS.
+#define RT_FLAT_QUOTA 16                           // leaf items a lane contributes per chunk
+#define RT_FLAT_ITEMS (64 * RT_FLAT_QUOTA)
+#define RT_FLAT_CAND 640                            // candidate items: < 64 left over + up to 64 x RT_LEAF new ones per round
+#define RT_FLAT_DWORDS (6 * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
+static_assert(RT_FLAT_CAND >= 64 + 64 * RT_LEAF, "one round of member tests must fit behind a partial round of candidates");
+
+template <bool DEBUG>
+DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayout &L, int polish, float *wl, bool mine,
+                              float ox, float oy, float oz, float dx, float dy, float dz,
+                              float &best_t, int &best_id, const Counters<DEBUG> &cnt)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = L.n;
+    float *ray = wl;                                                                // [6][64]
+    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(wl + 6 * 64);  // [64] smallest key per ray
+    unsigned long long *key2 = key1 + 64;                                           // [64] second smallest
+    unsigned short *items = reinterpret_cast<unsigned short *>(wl + 10 * 64);        // (ray << 8) | leaf
+    unsigned int *clist = reinterpret_cast<unsigned int *>(wl + 10 * 64 + RT_FLAT_ITEMS / 2);   // (ray << 16) | object
+    const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
+    const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
+    const int *kind = reinterpret_cast<const int *>(sc + L.off_kind);
+    constexpr unsigned long long NOKEY = ~0ull;
+
+    ray[lane] = ox; ray[64 + lane] = oy; ray[128 + lane] = oz;
+    ray[192 + lane] = dx; ray[256 + lane] = dy; ray[320 + lane] = dz;
+    key1[lane] = NOKEY; key2[lane] = NOKEY;
+    unsigned long long leaf_lo = 0, leaf_hi = 0;
+    if (mine) hierarchy_kept_leaves<DEBUG>(hl, L, ox, oy, oz, dx, dy, dz, leaf_lo, leaf_hi, cnt);
+
+    int ncand = 0;          // wave-uniform: candidate items waiting in clist
+    // exact intersections of the waiting candidates, 64 per round; partial rounds only when `all`
+    auto exact_rounds = [&](bool all) {
+        int done = 0;
+        while (ncand - done >= (all ? 1 : 64)) {
+            HSTAT(HS_CAND);
+            const int j = done + lane;
+            if (j < ncand) {
+                const unsigned int it = clist[j];
+                const int r = (int)(it >> 16), i = (int)(it & 0xffffu);
+                const float rox = ray[r], roy = ray[64 + r], roz = ray[128 + r];
+                const float rdx = ray[192 + r], rdy = ray[256 + r], rdz = ray[320 + r];
+                const float a = dot3(rdx, rdy, rdz, rdx, rdy, rdz);
+                const float *rec = sc + 8 * (i >> 1) + (i & 1);
+                const float ocx = rox - rec[0], ocy = roy - rec[2], ocz = roz - rec[4];
+                const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                const float c = oc2 - rec[6];
+                const float b = (ocz * rdz + ocy * rdy) + ocx * rdx;
+                float t; bool hit;
+                candidate_exact<DEBUG>(sc, L, polish, kind[i], a, ocx, ocy, ocz, b, c, rdx, rdy, rdz, t, hit, cnt);
+                if (hit && t < 1e30f) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)i;
+                    const unsigned long long old = atomicMin(&key1[r], key);
+                    const unsigned long long loser = old > key ? old : key;
+                    if (loser != NOKEY) atomicMin(&key2[r], loser);
+                }
+            }
+            done += 64;
+        }
+        // what is left (less than a round) moves to the front
+        const int rem = ncand - done;
+        if (rem > 0) {
+            unsigned int v = 0;
+            if (lane < rem) v = clist[done + lane];
+            if (lane < rem) clist[lane] = v;
+        }
+        ncand = rem > 0 ? rem : 0;
+    };
+
+    for (;;) {
+        // this chunk's items: up to RT_FLAT_QUOTA kept leaves per lane, at the lane's offset in the wave's list
+        int c = __popcll(leaf_lo) + __popcll(leaf_hi);
+        c = c < RT_FLAT_QUOTA ? c : RT_FLAT_QUOTA;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) break;
+        int at = incl - c;
+        for (int k = 0; k < c; ++k) {
+            int leaf;
+            if (leaf_lo) { leaf = __builtin_ctzll(leaf_lo); leaf_lo &= leaf_lo - 1; }
+            else { leaf = 64 + __builtin_ctzll(leaf_hi); leaf_hi &= leaf_hi - 1; }
+            items[at++] = (unsigned short)((lane << 8) | leaf);
+        }
+        for (int base = 0; base < total; base += 64) {
+            HSTAT(HS_LEAF);
+            const int j = base + lane;
+            const bool have = j < total;
+            const unsigned int it = items[have ? j : 0];
+            const int r = (int)(it >> 8), leaf = (int)(it & 0xffu);
+            const float rox = ray[r], roy = ray[64 + r], roz = ray[128 + r];
+            const float rdx = ray[192 + r], rdy = ray[256 + r], rdz = ray[320 + r];
+            const v2f OX = {rox, rox}, OY = {roy, roy}, OZ = {roz, roz};
+            const v2f DX = {rdx, rdx}, DY = {rdy, rdy}, DZ = {rdz, rdz};
+#pragma unroll
+            for (int m = 0; m < RT_LEAF / 2; ++m) {
+                const int mp = leaf * (RT_LEAF / 2) + m;
+                const float4 A = memb[2 * mp], B = memb[2 * mp + 1];
+                // the reference's bounding test (:399-402), operation for operation
+                v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, br2 = {B.z, B.w};
+                v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
+                v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                v2f cc = oc2 - br2;
+                v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
+                v2f disc = b * b - cc;
+                const unsigned int sid0 = slot_id[2 * mp], sid1 = slot_id[2 * mp + 1];
+                const bool p0 = have && !(disc.x < 0.0f) && !((sid0 & 0x8000u) && b.x > 0.0f && b.x < 1e15f && cc.x >= 0.0f);
+                const bool p1 = have && !(disc.y < 0.0f) && !((sid1 & 0x8000u) && b.y > 0.0f && b.y < 1e15f && cc.y >= 0.0f);
+                const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (p0) clist[ncand + __popcll(m0 & below)] = ((unsigned int)r << 16) | (sid0 & 0x7fffu);
+                ncand += __popcll(m0);
+                if (p1) clist[ncand + __popcll(m1 & below)] = ((unsigned int)r << 16) | (sid1 & 0x7fffu);
+                ncand += __popcll(m1);
+            }
+            if (ncand > RT_FLAT_CAND - 64 * RT_LEAF) exact_rounds(false);
+        }
+    }
+    exact_rounds(true);
+
+    float bt = 1e30f;
+    int bid = -1;
+    bool replay = false;
+    if (mine) {
+        const unsigned long long k1 = key1[lane];
+        if (k1 != NOKEY) {
+            const unsigned long long k2 = key2[lane];
+            bid = (int)(unsigned int)k1;
+            bt = __uint_as_float((unsigned int)(k1 >> 32));
+            if (k2 != NOKEY) {
+                // t_bound of the winner (:412): another hit in front of it could have made the reference skip it
+                const float *rec = sc + 8 * (bid >> 1) + (bid & 1);
+                const float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
+                const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                const float c = oc2 - rec[6];
+                const float b = (ocz * dz + ocy * dy) + ocx * dx;
+                const float t_bound = -b - rt_sqrt(b * b - c);
+                replay = __uint_as_float((unsigned int)(k2 >> 32)) < t_bound;
+            }
+        }
+    }
+    if (__ballot(replay) != 0ull) {
+        HSTAT(HS_SCAN);
+        if (replay) {
+            // the reference's loop as it stands
+            const float a = dot3(dx, dy, dz, dx, dy, dz);
+            bt = 1e30f; bid = -1;
+            for (int i = 0; i < n; ++i) {
+                const float *rec = sc + 8 * (i >> 1) + (i & 1);
+                const float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
+                const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                const float c = oc2 - rec[6];
+                const float b = (ocz * dz + ocy * dy) + ocx * dx;
+                const float disc = b * b - c;
+                if (disc < 0.0f) continue;
+                test_candidate<DEBUG>(sc, L, polish, i, a, ocx, ocy, ocz, b, c, disc, dx, dy, dz, bt, bid, cnt);
+            }
+        }
+    }
+    if (mine) {
+        offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
+        best_t = bt; best_id = bid;
+    }
 }
 
 // ------------------------------------------------------------------ one ray at a time, the whole wave on it
@@ -650,12 +874,14 @@ DEV void trace_cooperative(const float *sc, const SceneLayout &L, int polish, bo
     while (rays) {
         const int r = __builtin_ctzll(rays);
         rays &= rays - 1;
+        HSTAT(HS_COOP_RAY);
         const float rox = lane_value(ox, r), roy = lane_value(oy, r), roz = lane_value(oz, r);
         const float rdx = lane_value(dx, r), rdy = lane_value(dy, r), rdz = lane_value(dz, r);
         const float a = dot3(rdx, rdy, rdz, rdx, rdy, rdz);
         float bt = 1e30f;
         int bid = -1;
         for (int base = 0; base < n; base += 64) {
+            HSTAT(HS_COOP_ROUND);
             const int i = base + lane;
             const int ic = i < n ? i : n - 1;
             const float *rec = sc + 8 * (ic >> 1) + (ic & 1);

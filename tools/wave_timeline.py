@@ -42,7 +42,8 @@ def main():
         lib.rt_dev_wave_log_clear()
         assert lib.rt_render_device(ctypes.addressof(p), buf.data_ptr(), buf.numel(), None, 1) == 0, lib.rt_last_error()
         lib.rt_get_timing(ctypes.addressof(t))
-    log = np.zeros((8192, 4), dtype=np.uint64)
+    WORDS = 16      # RT_WAVE_LOG_WORDS
+    log = np.zeros((8192, WORDS), dtype=np.uint64)
     n = lib.rt_dev_wave_log(log.ctypes.data, 8192)
     log = log[:n]
     log = log[log[:, 1] > 0].astype(np.float64)
@@ -60,6 +61,12 @@ def main():
           f"pixels per wave: mean {px.mean():.0f} min {px.min():.0f} max {px.max():.0f}")
     us_per_trip = (log[:, 1] - log[:, 0]) / 100.0 / np.maximum(trips, 1)
     print(f"microseconds per loop trip: p10 {np.percentile(us_per_trip, 10):.2f}  p50 {np.percentile(us_per_trip, 50):.2f}  p90 {np.percentile(us_per_trip, 90):.2f}")
+    names = ["top-node loop", "leaf loop", "candidate loop (step 2)", "queue scan reads", "cooperative rays", "cooperative rounds"]
+    tot_trips = trips.sum()
+    print("hierarchy walk, loop iterations per loop trip of a wave (wave-level = instructions issued; lanes = mean lanes in it):")
+    for k, nm in enumerate(names):
+        wv, ln = log[:, 4 + k].sum(), log[:, 4 + len(names) + k].sum()
+        print(f"  {nm:26s} {wv / max(tot_trips, 1):8.2f} per trip   lanes per iteration {ln / max(wv, 1):6.1f}")
     last = np.argsort(log[:, 1])[-5:]
     print("the five last waves: end/span, trips, pixels: " + "; ".join(f"{end[i]:.3f} {int(trips[i])} {int(px[i])}" for i in last))
 
