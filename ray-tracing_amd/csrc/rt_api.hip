@@ -232,6 +232,8 @@ KParams make_kparams(const rt_params *p)
     // 2.2 ms with tiles, 3.3 ms spread; 256 spheres 1080p depth 16: 319 -> 172 ms spread).
     const bool deep = p->max_depth >= 12 && std::min(p->stack_size, p->max_depth - 1) >= 8 && k.use_hierarchy;
     k.spread_shift = deep ? 0 : 6;
+    // measured with four waves per SIMD: 256 spheres depth 16 at 1080p 136 -> 146 ms, at 4K 351 -> 332 ms
+    k.three_workgroups_per_cu = (deep && (long long)p->width * p->height < 4000000ll) ? 1 : 0;
     k.coop_rays = deep ? coop_rays_for(g.layout.n) : 0;
 #ifdef RT_DEV_SWITCHES
     if (const char *e = getenv("RT_SPREAD_SHIFT")) k.spread_shift = atoi(e);
@@ -266,12 +268,12 @@ int hierarchy_min_objects()
 
 // Rays a wave of the persistent hierarchy kernels may have left when it starts tracing them one at a
 // time with all 64 lanes (trace_cooperative: n / 64 rounds of object tests per ray, against one
-// hierarchy walk for all of the wave's rays together; measured best at 6 for 256 and for 1024 objects).
+// pooled hierarchy trace for all of the wave's rays together; measured best at 2-4 for 256 and for 1024 objects).
 int coop_rays_for(int n)
 {
     static_assert(RT_MAX_OBJECTS <= 1024, "the threshold was measured for up to 1024 objects (16 rounds per ray)");
     (void)n;
-    return 6;
+    return 3;
 }
 
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes

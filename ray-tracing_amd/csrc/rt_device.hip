@@ -74,6 +74,12 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 #ifndef RT_WAVES_PER_EU_HIER
 #define RT_WAVES_PER_EU_HIER 3
 #endif
+// single-sample hierarchy kernels: 128 VGPRs (two dwords spilled) for a fourth wave per SIMD, measured
+// 64 tori 4K 1.76 -> 1.58 ms, 256 spheres 4K depth 16 351 -> 332 ms; the multi-sample ones would spill
+// 23 dwords and lose 4 %
+#ifndef RT_WAVES_PER_EU_HIER1
+#define RT_WAVES_PER_EU_HIER1 4
+#endif
 #ifndef RT_WAVES_PER_EU_LDSP
 #define RT_WAVES_PER_EU_LDSP 4
 #endif
@@ -114,7 +120,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
 template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false>
-__global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU)
+__global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? (MULTI ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU_HIER1) : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
 {
@@ -819,6 +825,8 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS * 4 : (size_t)RT_QUEUE * 256 * 2);
+    // at most three workgroups per CU where the host asks for it: more than a quarter of the CU's LDS each
+    if (HIER && kp.three_workgroups_per_cu && lds < 41 * 1024) lds = 41 * 1024;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // the attribute is kept per device: set it when this variant first runs on a device
     static unsigned long long attr_devices = 0ull;       // bit d: set on device d

@@ -101,6 +101,8 @@ struct KParams {
     int use_hierarchy;      // walk the sphere hierarchy instead of the per-object loop
     int spread_shift;       // persistent kernels: log2 of the lanes that take neighbouring pixels (6: a wave's 64 pixels
     int spread_stride;      // are one 8x8 tile); smaller: groups from tiles spread_stride apart in the queue order
+    int three_workgroups_per_cu;   // hierarchy kernels: hold the occupancy at 3 waves per SIMD (small deep frames: the
+                            // frame waits for its longest waves, which run faster with fewer neighbours)
     int coop_rays;          // persistent hierarchy kernels: a wave with at most this many rays left traces them
                             // one at a time with all lanes (0: never)
 #ifdef RT_DEV_SWITCHES
