@@ -428,7 +428,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // [census: trace_call @ ITER]
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
-        if ((COOP || FLAT) && coop) { t = t_coop; id = id_coop; }
+        if (FLAT || (COOP && coop)) { t = t_coop; id = id_coop; }
         else if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
         else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
 
