@@ -144,7 +144,10 @@ size_t rt_output_bytes(const rt_params *p);
 /* Replaces glUniform*(camera) + glDrawArrays (main.py:277-280, :300) for a caller that
  * owns device memory: renders the current scene into `d_out` (device pointer) on
  * `stream` (a hipStream_t, or NULL for the library's stream) without synchronising.
- * With timed != 0 the kernel is bracketed by hipEvents read back by rt_get_timing.       */
+ * With timed != 0 the kernel is bracketed by hipEvents read back by rt_get_timing.  The library
+ * keeps ONE pair of events: rt_get_timing reports the most recent timed call, so time one call at
+ * a time (a second timed call issued before the first one's result has been read, on whatever
+ * stream, replaces it).                                                                  */
 int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed);
 
 /* rt_render_device for callers that cannot allocate device memory around the call (code under

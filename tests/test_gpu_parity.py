@@ -646,6 +646,26 @@ def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
     assert f32_identical(f32, ref)
 
 
+@pytest.mark.parametrize("which", ["spheres256_4k_d16", "mixed1024_8k_16spp"])
+def test_benchmark_sizes_hierarchy_kernels_equal_per_object_loop(gpu_rt, which):
+    """The two heaviest benchmark configurations at their full sizes, where the CPU oracle would
+    need many minutes: the frame of the hierarchy kernels (pooled trace; for the deep one also the
+    spread and the cooperative trace) must equal the frame of the plain per-object loop, the
+    reference's algorithm as it stands, which the smaller sizes pin against the oracle."""
+    if which == "spheres256_4k_d16":
+        scene, cam, w, h = gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 3840, 2160
+        o = dict(max_depth=16, stack_size=16, shadow_hops=4, out_f32=True)
+    else:
+        scene, cam, w, h = gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera(), 7680, 4320
+        o = dict(max_depth=8, stack_size=8, shadow_hops=2, spp_grid=4)
+    fast = gpu_rt.render_rgba(scene, cam, w, h, **o)
+    plain = gpu_rt.render_rgba(scene, cam, w, h, no_accel=True, **o)
+    if fast.dtype == np.float32:
+        assert f32_identical(fast, plain)
+    else:
+        assert np.array_equal(fast, plain)
+
+
 def test_largest_scene_blob_with_and_without_the_hierarchy(gpu_rt):
     """1024 tori = the largest blob (139 KB): the forced per-object loop has no LDS left for
     pending slots and must still run (workspace slots) and agree with the hierarchy kernels."""
