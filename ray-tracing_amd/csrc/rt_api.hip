@@ -14,7 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <string>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -73,11 +77,31 @@ struct State {
     char err[512] = "";
 } g;
 
+// Parts 1.. are issued by one thread each (bound to the part's device once), part 0 by the caller:
+// issuing a part costs the host about 0.04 ms (kernel launch, strided copy, events), which in
+// sequence would take longer than the frame's kernels run once there are eight parts.
+struct Issuers {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, finished;
+    unsigned long long generation = 0;      // bumped per frame
+    int pending = 0;                        // parts of this frame not issued yet
+    bool stop = false;
+    const rt_params *params = nullptr;      // the frame being issued
+    void *d_frame = nullptr;
+    std::vector<int> rc;                    // per part: result of the last issue
+    std::vector<std::string> err;           //           and its message
+} g_issuers;
+
+
+// where fail() writes: the library's message buffer, or the issuing thread's own one
+thread_local char *t_err = nullptr;
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g.err, sizeof g.err, fmt, ap);
+    vsnprintf(t_err ? t_err : g.err, sizeof g.err, fmt, ap);
     va_end(ap);
     return code;
 }
@@ -445,6 +469,16 @@ const char *rt_last_error(void) { return g.err; }
 
 static void release_parts()
 {
+    if (!g_issuers.threads.empty()) {
+        {
+            std::lock_guard<std::mutex> lk(g_issuers.m);
+            g_issuers.stop = true;
+        }
+        g_issuers.wake.notify_all();
+        for (auto &t : g_issuers.threads) t.join();
+        g_issuers.threads.clear();
+        g_issuers.stop = false;
+    }
     for (auto &pt : g.parts) {
         if (pt.device < 0) continue;
         (void)hipSetDevice(pt.device);
@@ -785,56 +819,107 @@ int rt_part_row_map(int height, int part, int nparts, int32_t *rows, int capacit
 // rt_init_multi mode: every part renders on its device; its bands go straight into the frame
 // `d_frame` on the first device (strided device-to-device copies over xGMI, no gather buffer and no
 // assemble pass); `s` (a stream of the first device) continues once all parts are in.
-static int render_multi(const rt_params *p, void *d_frame, hipStream_t s)
+// Render part i of the frame on its device and copy its bands into the frame on the first device.
+// The caller has made the part's device current.
+static int issue_part(int i, const rt_params *p, void *d_frame)
 {
     const int np = (int)g.parts.size();
-    if (p->nparts != 1 || p->part != 0) return fail(RT_E_ARG, "in multi-device mode the library splits the frame itself: part/nparts must be 0/1");
     const size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : (p->flags & RT_FLAG_OUT_RGB8) ? 3 : 4;
     const size_t row_bytes = (size_t)p->width * bpp, band_bytes = row_bytes * RT_BAND_ROWS;
     const int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
     const int tail_rows = p->height - (bands - 1) * RT_BAND_ROWS;          // rows of the last band (1..RT_BAND_ROWS)
+    State::Part &pt = g.parts[i];
+    rt_params q = *p;
+    q.part = i; q.nparts = np;
+    const size_t need = rt_output_bytes(&q);
+    if (need > pt.d_part_cap) {
+        if (pt.d_part) HIP_TRY(hipFree(pt.d_part));
+        pt.d_part = nullptr; pt.d_part_cap = 0;
+        HIP_TRY(hipMalloc(&pt.d_part, need ? need : 16));
+        pt.d_part_cap = need ? need : 16;
+    }
+    const int my_bands = (bands - i + np - 1) / np;
+    if (my_bands <= 0) { HIP_TRY(hipEventRecord(pt.done, pt.stream)); return RT_OK; }
+    KParams kp = make_kparams(&q);
+    kp.work_counter = pt.d_work;
+    kp.resident_workgroups = pt.resident_workgroups;
+    if (rt_uses_workspace(kp) && !pt.d_pend_ws) {
+        size_t ws = (size_t)pt.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_pend_ws), ws));
+    }
+    kp.pend_ws = pt.d_pend_ws;
+    HIP_TRY(hipStreamWaitEvent(pt.stream, g.parts[0].frame_free, 0));
+    LaunchInfo info{};
+    int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, i == 0 ? &info : nullptr)
+                                             : rt_strict::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, i == 0 ? &info : nullptr);
+    if (lrc) return fail(RT_E_HIP, "kernel launch failed on device %d: %s", pt.device, hipGetErrorString((hipError_t)lrc));
+    // bands i, i + np, ...: contiguous in the part buffer, np bands apart in the frame
+    const bool owns_tail = (bands - 1) % np == i && tail_rows != RT_BAND_ROWS;
+    const int full = owns_tail ? my_bands - 1 : my_bands;
+    char *dst = static_cast<char *>(d_frame) + (size_t)i * band_bytes;
+    if (full > 0)
+        HIP_TRY(hipMemcpy2DAsync(dst, band_bytes * np, pt.d_part, band_bytes, band_bytes, full, hipMemcpyDeviceToDevice, pt.stream));
+    if (owns_tail)
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)full * band_bytes * np, static_cast<char *>(pt.d_part) + (size_t)full * band_bytes,
+                               row_bytes * tail_rows, hipMemcpyDeviceToDevice, pt.stream));
+    HIP_TRY(hipEventRecord(pt.done, pt.stream));
+    if (i == 0) { g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap; }
+    return RT_OK;
+}
+
+// body of the thread that issues part i (i >= 1)
+static void issuer_main(int i)
+{
+    Issuers &is = g_issuers;
+    char err[sizeof g.err] = "";
+    t_err = err;
+    bool bound = hipSetDevice(g.parts[i].device) == hipSuccess;
+    unsigned long long seen = 0;
+    for (;;) {
+        const rt_params *p; void *d_frame;
+        {
+            std::unique_lock<std::mutex> lk(is.m);
+            is.wake.wait(lk, [&] { return is.stop || is.generation != seen; });
+            if (is.stop) return;
+            seen = is.generation;
+            p = is.params; d_frame = is.d_frame;
+        }
+        err[0] = 0;
+        int rc = !p ? fail(RT_E_STATE, "no frame to issue") : bound ? issue_part(i, p, d_frame) : fail(RT_E_HIP, "the issuing thread of part %d could not select device %d", i, g.parts[i].device);
+        {
+            std::lock_guard<std::mutex> lk(is.m);
+            is.rc[i] = rc;
+            is.err[i] = err;
+            if (--is.pending == 0) is.finished.notify_one();
+        }
+    }
+}
+
+static int render_multi(const rt_params *p, void *d_frame, hipStream_t s)
+{
+    const int np = (int)g.parts.size();
+    if (p->nparts != 1 || p->part != 0) return fail(RT_E_ARG, "in multi-device mode the library splits the frame itself: part/nparts must be 0/1");
+    Issuers &is = g_issuers;
     // the frame must not be overwritten before earlier work on `s` that reads it has run
     HIP_TRY(hipEventRecord(g.parts[0].frame_free, s));
-    for (int i = 0; i < np; ++i) {
-        State::Part &pt = g.parts[i];
-        rt_params q = *p;
-        q.part = i; q.nparts = np;
-        const size_t need = rt_output_bytes(&q);
-        HIP_TRY(hipSetDevice(pt.device));
-        if (need > pt.d_part_cap) {
-            if (pt.d_part) HIP_TRY(hipFree(pt.d_part));
-            pt.d_part = nullptr; pt.d_part_cap = 0;
-            HIP_TRY(hipMalloc(&pt.d_part, need ? need : 16));
-            pt.d_part_cap = need ? need : 16;
-        }
-        const int my_bands = (bands - i + np - 1) / np;
-        if (my_bands <= 0) { HIP_TRY(hipEventRecord(pt.done, pt.stream)); continue; }
-        KParams kp = make_kparams(&q);
-        kp.work_counter = pt.d_work;
-        kp.resident_workgroups = pt.resident_workgroups;
-        if (rt_uses_workspace(kp) && !pt.d_pend_ws) {
-            size_t ws = (size_t)pt.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_pend_ws), ws));
-        }
-        kp.pend_ws = pt.d_pend_ws;
-        HIP_TRY(hipStreamWaitEvent(pt.stream, g.parts[0].frame_free, 0));
-        LaunchInfo info{};
-        int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, &info)
-                                                 : rt_strict::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, &info);
-        if (lrc) return fail(RT_E_HIP, "kernel launch failed on device %d: %s", pt.device, hipGetErrorString((hipError_t)lrc));
-        // bands i, i + np, ...: contiguous in the part buffer, np bands apart in the frame
-        const bool owns_tail = (bands - 1) % np == i && tail_rows != RT_BAND_ROWS;
-        const int full = owns_tail ? my_bands - 1 : my_bands;
-        char *dst = static_cast<char *>(d_frame) + (size_t)i * band_bytes;
-        if (full > 0)
-            HIP_TRY(hipMemcpy2DAsync(dst, band_bytes * np, pt.d_part, band_bytes, band_bytes, full, hipMemcpyDeviceToDevice, pt.stream));
-        if (owns_tail)
-            HIP_TRY(hipMemcpyAsync(dst + (size_t)full * band_bytes * np, static_cast<char *>(pt.d_part) + (size_t)full * band_bytes,
-                                   row_bytes * tail_rows, hipMemcpyDeviceToDevice, pt.stream));
-        HIP_TRY(hipEventRecord(pt.done, pt.stream));
-        if (i == 0) { g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap; }
+    if (np > 1) {
+        std::lock_guard<std::mutex> lk(is.m);
+        is.params = p; is.d_frame = d_frame;
+        is.pending = np - 1;
+        is.generation++;
+    }
+    if (np > 1) is.wake.notify_all();
+    // (no early return from here to the wait below: the issuing threads hold `p`)
+    int rc = hipSetDevice(g.parts[0].device) == hipSuccess ? issue_part(0, p, d_frame)
+                                                            : fail(RT_E_HIP, "cannot select device %d", g.parts[0].device);
+    if (np > 1) {
+        std::unique_lock<std::mutex> lk(is.m);
+        is.finished.wait(lk, [&] { return is.pending == 0; });
+        for (int i = 1; i < np && !rc; ++i)
+            if (is.rc[i]) { rc = is.rc[i]; snprintf(g.err, sizeof g.err, "%s", is.err[i].c_str()); }
     }
     HIP_TRY(hipSetDevice(g.device));
+    if (rc) return rc;
     for (int i = 0; i < np; ++i) HIP_TRY(hipStreamWaitEvent(s, g.parts[i].done, 0));
     return RT_OK;
 }
@@ -879,6 +964,15 @@ int rt_init_multi_devices(const int *devices, int n)
     }
     if (rc) { char err[sizeof g.err]; std::memcpy(err, g.err, sizeof err); rt_shutdown(); std::memcpy(g.err, err, sizeof err); return rc; }
     HIP_TRY(hipSetDevice(g.device));
+    // no issuing thread is alive here: a fresh generation count, so that the new threads (which start
+    // at generation 0) do not take the last frame of an earlier initialisation for a job
+    g_issuers.stop = false;
+    g_issuers.generation = 0;
+    g_issuers.pending = 0;
+    g_issuers.params = nullptr; g_issuers.d_frame = nullptr;
+    g_issuers.rc.assign(n, 0);
+    g_issuers.err.assign(n, std::string());
+    for (int i = 1; i < n; ++i) g_issuers.threads.emplace_back(issuer_main, i);
     return RT_OK;
 }
 

@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "rt_types.h"
 
@@ -829,14 +830,15 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if (HIER && kp.three_workgroups_per_cu && lds < 41 * 1024) lds = 41 * 1024;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // the attribute is kept per device: set it when this variant first runs on a device
-    static unsigned long long attr_devices = 0ull;       // bit d: set on device d
+    // (launches of one variant may come from several threads, one per device)
+    static std::atomic<unsigned long long> attr_devices{0ull};       // bit d: set on device d
     int cur_device = -1;
     if (hipGetDevice(&cur_device) != hipSuccess || cur_device < 0 || cur_device > 63) return (int)hipErrorInvalidDevice;
-    if (!((attr_devices >> cur_device) & 1ull)) {
+    if (!((attr_devices.load(std::memory_order_acquire) >> cur_device) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_devices |= 1ull << cur_device;
+        attr_devices.fetch_or(1ull << cur_device, std::memory_order_release);
     }
     int bands = (kp.h + 15) / 16;
     int my_bands = (bands - kp.part + kp.nparts - 1) / kp.nparts;
@@ -856,8 +858,13 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (info) {
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn)) == hipSuccess) info->vgprs = fa.numRegs;
+        // (asked once per variant: the query costs the host as much as a launch)
+        static std::atomic<int> vgprs{-1};
+        if (vgprs.load(std::memory_order_relaxed) < 0) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn)) == hipSuccess) vgprs.store(fa.numRegs, std::memory_order_relaxed);
+        }
+        info->vgprs = vgprs.load(std::memory_order_relaxed) < 0 ? 0 : vgprs.load(std::memory_order_relaxed);
         info->lds_bytes = (int)lds;
         info->pending_cap = CAP;
     }
