@@ -511,60 +511,83 @@ DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v
     keep1 = !(s.y < 0.0f) && !behind1;
 }
 
+// Growth, slack and behind-limit of the node test for one ray (see the comment above node_keep).
+struct NodeTest { float grow, slack, behind_scale; };
+DEV NodeTest node_test_constants(const SceneLayout &L, float ox, float oy, float oz, float a)
+{
+    // every object and node lies inside the scene sphere (L.hc, L.hR), so |oc| + R <= reach = |o - hc| + hR for all of them
+    float sf2 = 2.5e-6f + 1.1f * __builtin_fabsf(a - 1.0f);
+    const float sf = __builtin_amdgcn_sqrtf(sf2) * 1.02f;
+    const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
+    const float reach = (__builtin_amdgcn_sqrtf((qz * qz + qy * qy) + qx * qx) + L.hR) * 1.0001f;
+    NodeTest nt;
+    nt.grow = sf * reach;
+    nt.slack = (sf2 * 1.05f) * (reach * reach + (reach + nt.grow) * (reach + nt.grow)) + 1e-30f;
+    // all-sphere nodes behind the origin are skipped, for ordinary rays only (else the limit is +inf)
+    const bool shortcut_ok = a > 0.5f && a < 2.0f && reach < 1e12f;
+    nt.behind_scale = shortcut_ok ? (a > 1.0f ? a : 1.0f) * 1.0001f : __builtin_inff();
+    return nt;
+}
+// bit j: top node j is kept.  hl = the hierarchy sections in LDS, starting at the top nodes.
+DEV unsigned int kept_top_nodes(const float *hl, const SceneLayout &L, const NodeTest &nt,
+                                float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+    const float4 *top = reinterpret_cast<const float4 *>(hl);
+    const int n2 = L.n2;
+    unsigned int top_mask = 0;
+    for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
+        bool k0, k1;
+        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, nt.grow, nt.slack, nt.behind_scale, k0, k1);
+        top_mask |= (k0 ? 1u : 0u) << (2 * j);
+        top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
+    }
+    return top_mask;
+}
+// bit k: leaf node tn * RT_FAN + k (one of the RT_FAN leaf nodes under top node tn) is kept
+DEV unsigned int kept_leaves_under(const float *hl, const SceneLayout &L, const NodeTest &nt, int tn,
+                                   float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
+    const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
+    const int n1 = L.n1;
+    const int last_leaf_pair = (n1 - 1) >> 1;
+    const int first = tn * RT_FAN;                       // first leaf node of this top node
+    const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
+    unsigned int bits = 0;
+#pragma unroll
+    for (int kk = 0; kk < RT_FAN / 2; ++kk) {
+        int lp = (first >> 1) + kk;
+        lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
+        bool k0, k1;
+        node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, nt.grow, nt.slack, nt.behind_scale, k0, k1);
+        bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
+        bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
+    }
+    return bits;
+}
+
 // Step 1 down to the leaf level: bit masks of the leaf nodes this lane's ray keeps (0..63 / 64..127).
+// The top nodes are tested by all lanes together; below them every lane walks its own list of
+// kept nodes (bit masks), so a wave of incoherent rays pays for the longest list of any lane,
+// not for the union of all lists.
 template <bool DEBUG>
 DEV void hierarchy_kept_leaves(const float *hl, const SceneLayout &L,
                                float ox, float oy, float oz, float dx, float dy, float dz,
                                unsigned long long &leaf_lo_out, unsigned long long &leaf_hi_out, const Counters<DEBUG> &cnt)
 {
     const float a = dot3(dx, dy, dz, dx, dy, dz);    // intersect_sphere's dot(d,d) (:78)
-    const int n1 = L.n1, n2 = L.n2;
-    const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
-    const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
-    // growth and slack of the node test, once per ray: every object and node lies inside the
-    // scene sphere (L.hc, L.hR), so |oc| + R <= reach = |o - hc| + hR for all of them
-    float sf2 = 2.5e-6f + 1.1f * __builtin_fabsf(a - 1.0f);
-    const float sf = __builtin_amdgcn_sqrtf(sf2) * 1.02f;
-    const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
-    const float reach = (__builtin_amdgcn_sqrtf((qz * qz + qy * qy) + qx * qx) + L.hR) * 1.0001f;
-    const float grow = sf * reach;
-    const float slack = (sf2 * 1.05f) * (reach * reach + (reach + grow) * (reach + grow)) + 1e-30f;
-    // all-sphere nodes behind the origin are skipped, for ordinary rays only (else the limit is +inf)
-    const bool shortcut_ok = a > 0.5f && a < 2.0f && reach < 1e12f;
-    const float behind_scale = shortcut_ok ? (a > 1.0f ? a : 1.0f) * 1.0001f : __builtin_inff();
-    // hl = the hierarchy sections in LDS, starting at the top nodes
-    const float4 *top = reinterpret_cast<const float4 *>(hl);
-    const float4 *leafn = reinterpret_cast<const float4 *>(hl + (L.off_leaf - L.off_top));
-
-    // ---- step 1: collect the objects whose bounding test passes.
-    // The top nodes are tested by all lanes together; below them every lane walks its own
-    // list of kept nodes (bit masks), so a wave of incoherent rays pays for the longest list
-    // of any lane, not for the union of all lists.
-    unsigned int top_mask = 0;
-    for (int j = 0; j < ((n2 + 1) >> 1); ++j) {
-        bool k0, k1;
-        node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, behind_scale, k0, k1);
-        top_mask |= (k0 ? 1u : 0u) << (2 * j);
-        top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
-    }
+    const NodeTest nt = node_test_constants(L, ox, oy, oz, a);
+    unsigned int top_mask = kept_top_nodes(hl, L, nt, ox, oy, oz, dx, dy, dz);
     unsigned long long leaf_lo = 0, leaf_hi = 0;        // kept leaf nodes 0..63 / 64..127
-    const int last_leaf_pair = (n1 - 1) >> 1;
     while (top_mask) {
         HSTAT(HS_TOP);
         const int tn = __builtin_ctz(top_mask);
         top_mask &= top_mask - 1;
-        const int first = tn * RT_FAN;                       // first leaf node of this top node
-        const int nleaf = (n1 - first < RT_FAN) ? n1 - first : RT_FAN;
-        unsigned int bits = 0;
-#pragma unroll
-        for (int kk = 0; kk < RT_FAN / 2; ++kk) {
-            int lp = (first >> 1) + kk;
-            lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
-            bool k0, k1;
-            node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, grow, slack, behind_scale, k0, k1);
-            bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
-            bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
-        }
+        const unsigned int bits = kept_leaves_under(hl, L, nt, tn, ox, oy, oz, dx, dy, dz);
+        const int first = tn * RT_FAN;
         const unsigned long long placed = (unsigned long long)bits << (first & 63);
         if (first < 64) leaf_lo |= placed; else leaf_hi |= placed;
     }
@@ -681,7 +704,14 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
 #define RT_FLAT_QUOTA 16                           // leaf items a lane contributes per chunk
 #define RT_FLAT_ITEMS (64 * RT_FLAT_QUOTA)
 #define RT_FLAT_CAND 640                            // candidate items: < 64 left over + up to 64 x RT_LEAF new ones per round
-#define RT_FLAT_DWORDS (6 * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
+// 1: the top-node loop is pooled as well ((ray, top node) items).  Measured against 0 in one call:
+// 1024 objects 8K 16 spp 1255 -> 1220 ms and 1080p 8.5 -> 8.2 ms, but 64 tori 4K 1.55 -> 1.68 ms and
+// 256 spheres 4K depth 16 327 -> 342 ms (92 items per trace fill 1.4 rounds, the item traffic and 17
+// spilled dwords cost more than the 3 iterations at 29 lanes they replace), so it is off.
+#ifndef RT_FLAT_TOP
+#define RT_FLAT_TOP 0
+#endif
+#define RT_FLAT_DWORDS (9 * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
 static_assert(RT_FLAT_CAND >= 64 + 64 * RT_LEAF, "one round of member tests must fit behind a partial round of candidates");
 
 template <bool DEBUG>
@@ -691,11 +721,11 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
 {
     const int lane = (int)(threadIdx.x & 63u);
     const int n = L.n;
-    float *ray = wl;                                                                // [6][64]
-    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(wl + 6 * 64);  // [64] smallest key per ray
+    float *ray = wl;                                                                // [9][64]: origin, direction, node-test constants
+    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(wl + 9 * 64);  // [64] smallest key per ray
     unsigned long long *key2 = key1 + 64;                                           // [64] second smallest
-    unsigned short *items = reinterpret_cast<unsigned short *>(wl + 10 * 64);        // (ray << 8) | leaf
-    unsigned int *clist = reinterpret_cast<unsigned int *>(wl + 10 * 64 + RT_FLAT_ITEMS / 2);   // (ray << 16) | object
+    unsigned short *items = reinterpret_cast<unsigned short *>(wl + 13 * 64);        // (ray << 8) | leaf (or top node)
+    unsigned int *clist = reinterpret_cast<unsigned int *>(wl + 13 * 64 + RT_FLAT_ITEMS / 2);   // (ray << 16) | object
     const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
     const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
     const int *kind = reinterpret_cast<const int *>(sc + L.off_kind);
@@ -705,7 +735,56 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     ray[192 + lane] = dx; ray[256 + lane] = dy; ray[320 + lane] = dz;
     key1[lane] = NOKEY; key2[lane] = NOKEY;
     unsigned long long leaf_lo = 0, leaf_hi = 0;
+#if RT_FLAT_TOP
+    // The leaf nodes under the kept top nodes, pooled like the rest: (ray, top node) items; the
+    // kept leaves are OR-ed into the ray's two mask words, which live in the candidate list's
+    // memory (unused until the leaf rounds).
+    {
+        unsigned long long *lmask = reinterpret_cast<unsigned long long *>(clist);      // [64][2]
+        unsigned int top_mask = 0;
+        NodeTest nt = {0.0f, 0.0f, 0.0f};
+        if (mine) {
+            nt = node_test_constants(L, ox, oy, oz, dot3(dx, dy, dz, dx, dy, dz));
+            top_mask = kept_top_nodes(hl, L, nt, ox, oy, oz, dx, dy, dz);
+        }
+        ray[384 + lane] = nt.grow; ray[448 + lane] = nt.slack; ray[512 + lane] = nt.behind_scale;
+        lmask[2 * lane] = 0ull; lmask[2 * lane + 1] = 0ull;
+        for (;;) {
+            int c = __popc(top_mask);
+            c = c < RT_FLAT_QUOTA ? c : RT_FLAT_QUOTA;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) break;
+            int at = incl - c;
+            for (int k = 0; k < c; ++k) {
+                const int tn = __builtin_ctz(top_mask);
+                top_mask &= top_mask - 1;
+                items[at++] = (unsigned short)((lane << 8) | tn);
+            }
+            for (int base = 0; base < total; base += 64) {
+                HSTAT(HS_TOP);
+                const int j = base + lane;
+                if (j < total) {
+                    const unsigned int it = items[j];
+                    const int r = (int)(it >> 8), tn = (int)(it & 0xffu);
+                    const NodeTest rnt = {ray[384 + r], ray[448 + r], ray[512 + r]};
+                    const unsigned int bits = kept_leaves_under(hl, L, rnt, tn, ray[r], ray[64 + r], ray[128 + r],
+                                                                ray[192 + r], ray[256 + r], ray[320 + r]);
+                    const int first = tn * RT_FAN;
+                    if (bits) atomicOr(&lmask[2 * r + (first >> 6)], (unsigned long long)bits << (first & 63));
+                }
+            }
+        }
+        leaf_lo = lmask[2 * lane]; leaf_hi = lmask[2 * lane + 1];
+    }
+#else
     if (mine) hierarchy_kept_leaves<DEBUG>(hl, L, ox, oy, oz, dx, dy, dz, leaf_lo, leaf_hi, cnt);
+#endif
 
     int ncand = 0;          // wave-uniform: candidate items waiting in clist
     // exact intersections of the waiting candidates, 64 per round; partial rounds only when `all`
