@@ -491,6 +491,7 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
 //
 // The candidates are queued per ray in LDS as 16-bit object indices; a ray that collects
 // more than RT_QUEUE of them walks all objects in step 2 instead (same result, slower).
+// [census: node_keep @ 0]
 DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v2f DZ, float grow, float slack,
                    float behind_scale, bool &keep0, bool &keep1)
 {
@@ -512,6 +513,7 @@ DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v
 }
 
 // Growth, slack and behind-limit of the node test for one ray (see the comment above node_keep).
+// [census: node_constants @ ITER]
 struct NodeTest { float grow, slack, behind_scale; };
 DEV NodeTest node_test_constants(const SceneLayout &L, float ox, float oy, float oz, float a)
 {
@@ -528,6 +530,7 @@ DEV NodeTest node_test_constants(const SceneLayout &L, float ox, float oy, float
     nt.behind_scale = shortcut_ok ? (a > 1.0f ? a : 1.0f) * 1.0001f : __builtin_inff();
     return nt;
 }
+// [census: top_nodes @ ITER]
 // bit j: top node j is kept.  hl = the hierarchy sections in LDS, starting at the top nodes.
 DEV unsigned int kept_top_nodes(const float *hl, const SceneLayout &L, const NodeTest &nt,
                                 float ox, float oy, float oz, float dx, float dy, float dz)
@@ -545,6 +548,7 @@ DEV unsigned int kept_top_nodes(const float *hl, const SceneLayout &L, const Nod
     }
     return top_mask;
 }
+// [census: leaves_under_top @ TOP]
 // bit k: leaf node tn * RT_FAN + k (one of the RT_FAN leaf nodes under top node tn) is kept
 DEV unsigned int kept_leaves_under(const float *hl, const SceneLayout &L, const NodeTest &nt, int tn,
                                    float ox, float oy, float oz, float dx, float dy, float dz)
@@ -719,6 +723,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
                               float ox, float oy, float oz, float dx, float dy, float dz,
                               float &best_t, int &best_id, const Counters<DEBUG> &cnt)
 {
+    // [census: flat_setup @ ITER]
     const int lane = (int)(threadIdx.x & 63u);
     const int n = L.n;
     float *ray = wl;                                                                // [9][64]: origin, direction, node-test constants
@@ -791,6 +796,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     auto exact_rounds = [&](bool all) {
         int done = 0;
         while (ncand - done >= (all ? 1 : 64)) {
+            // [census: flat_exact_round @ FLAT_EXACT]
             HSTAT(HS_CAND);
             const int j = done + lane;
             if (j < ncand) {
@@ -816,6 +822,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             done += 64;
         }
         // what is left (less than a round) moves to the front
+        // [census: flat_exact_compact @ ITER]
         const int rem = ncand - done;
         if (rem > 0) {
             unsigned int v = 0;
@@ -827,6 +834,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
 
     for (;;) {
         // this chunk's items: up to RT_FLAT_QUOTA kept leaves per lane, at the lane's offset in the wave's list
+        // [census: flat_items @ ITER]
         int c = __popcll(leaf_lo) + __popcll(leaf_hi);
         c = c < RT_FLAT_QUOTA ? c : RT_FLAT_QUOTA;
         int incl = c;
@@ -845,6 +853,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             items[at++] = (unsigned short)((lane << 8) | leaf);
         }
         for (int base = 0; base < total; base += 64) {
+            // [census: flat_leaf_round @ FLAT_LEAF]
             HSTAT(HS_LEAF);
             const int j = base + lane;
             const bool have = j < total;
@@ -880,6 +889,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     }
     exact_rounds(true);
 
+    // [census: flat_owner @ ITER]
     float bt = 1e30f;
     int bid = -1;
     bool replay = false;
@@ -902,6 +912,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
         }
     }
     if (__ballot(replay) != 0ull) {
+        // [census: flat_replay @ 0]
         HSTAT(HS_SCAN);
         if (replay) {
             // the reference's loop as it stands
@@ -919,6 +930,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             }
         }
     }
+    // [census: flat_end @ ITER]
     if (mine) {
         offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
         best_t = bt; best_id = bid;
