@@ -10,13 +10,14 @@
 //
 // Design (wave64, VALU-bound, no MFMA: there is no dense contraction in this workload):
 //   * one lane = one pixel at a time; a wave owns an 8x8 pixel tile.  Small scenes: one tile per
-//     wave and launch, 256-thread workgroup = 16x16 pixels.  Large scenes and deep stacks:
-//     persistent waves that take tiles from a work queue (REFILL below).
+//     wave and launch, one wave per workgroup.  Large scenes and deep stacks: persistent waves that
+//     take tiles from a work queue (REFILL below).
 //   * the scene is staged once per workgroup in LDS, split so that the per-object hot loop
 //     reads one 16-byte record (centre + bounding radius^2) as an LDS broadcast; torus
 //     frames, kinds and materials sit behind the bounding test / the closest-hit decision.
 //     Scenes of 40+ objects are traced through a sphere hierarchy that returns exactly the
-//     per-object loop's hits (rt_intersect.h).
+//     per-object loop's hits, with the member tests and exact intersections of a wave's 64 rays
+//     pooled in LDS and dealt out evenly over the lanes (rt_intersect.h).
 //   * trace() keeps only (t, id) of the closest hit; position, normal and material are
 //     derived once for the winner (the reference builds a full HitInfo per candidate,
 //     fragment_shader.glsl:416-425; only the winner's is ever read).
@@ -88,7 +89,8 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // MULTI: more than one sample per pixel (sample loop + accumulators); the single-sample
 // kernel carries neither.
 // HIER: trace through the sphere hierarchy (large scenes); only the hierarchy sections and the
-// per-lane candidate queues are in LDS, the rest of the scene is read from global memory.
+// waves' work lists (RT_FLAT; per-lane candidate queues without it) are in LDS, the rest of the
+// scene is read from global memory.
 // REFILL: persistent waves behind a work queue.  The frame is a queue of 8x8 tiles in
 // RT_SUBQUEUES interleaved sub-queues; a wave takes a tile, and whenever lanes finish their
 // pixel they are handed the next unassigned pixels of the wave's current tile (ballot + prefix

@@ -1,6 +1,9 @@
-// rt_intersect.h -- event counters, the torus solve, the candidate tests and the two forms of
-// trace (per-object loop, sphere hierarchy).  Included by rt_device.hip after rt_numerics.h;
-// not a stand-alone header.
+// rt_intersect.h -- event counters, the torus solve, the candidate tests and the forms of trace:
+// the per-object loop (trace_closest), the sphere hierarchy with every lane walking its own lists
+// (trace_hierarchy), the same with the wave's work pooled in LDS (trace_hierarchy_flat, what the
+// large-scene kernels run) and one ray at a time on all lanes (trace_cooperative, the last rays of
+// a wave in deep frames).  All return the reference loop's (t, id) bit for bit.  Included by
+// rt_device.hip after rt_numerics.h; not a stand-alone header.
 #pragma once
 
 namespace RT_NS {
