@@ -255,6 +255,13 @@ KParams make_kparams(const rt_params *p)
     // wave: there the coherence of neighbouring primary rays is worth more (64 tori 4K depth 8:
     // 2.2 ms with tiles, 3.3 ms spread; 256 spheres 1080p depth 16: 319 -> 172 ms spread).
     const bool deep = p->max_depth >= 12 && std::min(p->stack_size, p->max_depth - 1) >= 8 && k.use_hierarchy;
+    // The pooled trace has a fixed cost per trace (ray table, prefix sums, per-ray keys) that a cheap
+    // walk does not earn back.  Same-call A/B against per-lane lists (4K unless noted): 48 objects
+    // depth 4 +17 %, 96 objects depth 4 / 8 +11 / +5 %; 256 objects depth 8 -10 %, 256 spheres 1080p
+    // depth 8 -23 %, 1024 objects depth 8 -20 % (long, uneven leaf lists); 64 tori depth 4 / 8
+    // -8 / -17 % (few leaves, but the torus intersections of a wave fill 1.4 rounds instead of 2.8
+    // iterations with 21 lanes).
+    k.pooled_trace = (deep || g.layout.n >= 192 || g.layout.ntori >= 48) ? 1 : 0;
     k.spread_shift = deep ? 0 : 6;
     // measured with four waves per SIMD: 256 spheres depth 16 at 1080p 136 -> 146 ms, at 4K 351 -> 332 ms
     k.three_workgroups_per_cu = (deep && (long long)p->width * p->height < 4000000ll) ? 1 : 0;

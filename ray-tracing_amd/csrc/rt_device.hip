@@ -98,6 +98,9 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // magnitude between neighbouring pixels at depth 16, so without this most lanes of a wave
 // wait for its longest pixel.  With kp.whole_tiles the pixels are handed out only when the
 // whole wave is idle: tile after tile with the lanes in lock-step (small scenes).
+// POOL (hierarchy kernels): the member tests and exact intersections of a wave's rays are pooled
+// (trace_hierarchy_flat); without it every lane walks its own lists (trace_hierarchy), which has less
+// fixed cost per trace and is what small scenes of cheap objects run.
 // DEEP (persistent hierarchy kernels): the code for frames of deep path trees -- a wave's pixels
 // come from 64 different tiles (kp.spread_shift / kp.spread_stride), and a wave with at most
 // kp.coop_rays rays left traces them one at a time with all lanes (trace_cooperative).
@@ -122,7 +125,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_WG_ONE 64
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true>
 __global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? (MULTI ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU_HIER1) : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
@@ -411,7 +414,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         // A wave that is down to its last few rays (deep pixels, nothing left to refill with) puts
         // all of its lanes on one ray at a time instead of walking the hierarchy with most lanes idle.
         constexpr bool COOP = DEEP;
-        constexpr bool FLAT = HIER && REFILL && !DEBUG && RT_FLAT;
+        constexpr bool FLAT = HIER && REFILL && !DEBUG && POOL && RT_FLAT;
         float t_coop = 0.0f; int id_coop = -1;
         bool coop = false;      // this trip's trace is done here, by the whole wave (wave-uniform)
         if (COOP) {
@@ -812,7 +815,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 __global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
@@ -823,11 +826,12 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if ((PEND == PEND_GLOBAL || PEND == PEND_HYBRID) && !kp.pend_ws) return (int)hipErrorInvalidValue;
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     static_assert(!DEEP || (HIER && REFILL && !DEBUG), "the deep-frame code belongs to the persistent hierarchy kernels");
-    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP>;
+    static_assert(POOL || !DEEP, "deep frames always pool");
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
-    if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS * 4 : (size_t)RT_QUEUE * 256 * 2);
+    if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && POOL && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS * 4 : (size_t)RT_QUEUE * 256 * 2);
     // at most three workgroups per CU where the host asks for it: more than a quarter of the CU's LDS each
     if (HIER && kp.three_workgroups_per_cu && lds < 41 * 1024) lds = 41 * 1024;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
@@ -886,14 +890,17 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
     // deep frames (the host's choice, see make_kparams): pixels spread over waves + cooperative trace
     const bool deep = kp.coop_rays > 0 || kp.spread_shift < 6;
+    const bool pool = kp.pooled_trace != 0;         // (the host's choice as well)
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
            : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
 #define RT_LAUNCH_HIER(CAP_, PEND_)                                                                         \
     (deep ? (multi ? launch_variant<CAP_, false, PEND_, true, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)  \
                    : launch_variant<CAP_, false, PEND_, false, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)) \
-          : (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)        \
-                   : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)))
+     : pool ? (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)        \
+                     : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info))      \
+            : (multi ? launch_variant<CAP_, false, PEND_, true, true, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info)  \
+                     : launch_variant<CAP_, false, PEND_, false, true, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info)))
     // Large scenes run as persistent waves with pixel refill (measured 1.1-2.4x there: 64 tori
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
     // 2250 -> 928 ms).  The 5-object scene keeps one pixel per lane: there the lanes' loss of
