@@ -718,7 +718,8 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
 #ifndef RT_FLAT_TOP
 #define RT_FLAT_TOP 0
 #endif
-#define RT_FLAT_DWORDS (9 * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
+#define RT_FLAT_RAY_FIELDS (RT_FLAT_TOP ? 9 : 6)     // origin, direction (+ the node-test constants)
+#define RT_FLAT_DWORDS (RT_FLAT_RAY_FIELDS * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
 static_assert(RT_FLAT_CAND >= 64 + 64 * RT_LEAF, "one round of member tests must fit behind a partial round of candidates");
 
 template <bool DEBUG>
@@ -729,11 +730,11 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     // [census: flat_setup @ ITER]
     const int lane = (int)(threadIdx.x & 63u);
     const int n = L.n;
-    float *ray = wl;                                                                // [9][64]: origin, direction, node-test constants
-    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(wl + 9 * 64);  // [64] smallest key per ray
+    float *ray = wl;                                                                // [RT_FLAT_RAY_FIELDS][64]
+    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(wl + RT_FLAT_RAY_FIELDS * 64);  // [64] smallest key per ray
     unsigned long long *key2 = key1 + 64;                                           // [64] second smallest
-    unsigned short *items = reinterpret_cast<unsigned short *>(wl + 13 * 64);        // (ray << 8) | leaf (or top node)
-    unsigned int *clist = reinterpret_cast<unsigned int *>(wl + 13 * 64 + RT_FLAT_ITEMS / 2);   // (ray << 16) | object
+    unsigned short *items = reinterpret_cast<unsigned short *>(wl + (RT_FLAT_RAY_FIELDS + 4) * 64);   // (ray << 8) | leaf (or top node)
+    unsigned int *clist = reinterpret_cast<unsigned int *>(wl + (RT_FLAT_RAY_FIELDS + 4) * 64 + RT_FLAT_ITEMS / 2);   // (ray << 16) | object
     const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
     const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
     const int *kind = reinterpret_cast<const int *>(sc + L.off_kind);
