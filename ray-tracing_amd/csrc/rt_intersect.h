@@ -547,9 +547,9 @@ DEV unsigned int kept_top_nodes(const float *hl, const SceneLayout &L, const Nod
         bool k0, k1;
         node_keep(top[2 * j], top[2 * j + 1], OX, OY, OZ, DX, DY, DZ, nt.grow, nt.slack, nt.behind_scale, k0, k1);
         top_mask |= (k0 ? 1u : 0u) << (2 * j);
-        top_mask |= ((k1 && 2 * j + 1 < n2) ? 2u : 0u) << (2 * j);
+        top_mask |= (k1 ? 2u : 0u) << (2 * j);
     }
-    return top_mask;
+    return top_mask & (n2 >= 32 ? ~0u : (1u << n2) - 1u);
 }
 // [census: leaves_under_top @ TOP]
 // bit k: leaf node tn * RT_FAN + k (one of the RT_FAN leaf nodes under top node tn) is kept
@@ -570,10 +570,10 @@ DEV unsigned int kept_leaves_under(const float *hl, const SceneLayout &L, const 
         lp = lp < last_leaf_pair ? lp : last_leaf_pair;   // stay inside the section; masked below
         bool k0, k1;
         node_keep(leafn[2 * lp], leafn[2 * lp + 1], OX, OY, OZ, DX, DY, DZ, nt.grow, nt.slack, nt.behind_scale, k0, k1);
-        bits |= ((k0 && 2 * kk < nleaf) ? 1u : 0u) << (2 * kk);
-        bits |= ((k1 && 2 * kk + 1 < nleaf) ? 2u : 0u) << (2 * kk);
+        bits |= (k0 ? 1u : 0u) << (2 * kk);
+        bits |= (k1 ? 2u : 0u) << (2 * kk);
     }
-    return bits;
+    return bits & ((1u << nleaf) - 1u);     // the last top node may have fewer than RT_FAN leaf nodes
 }
 
 // Step 1 down to the leaf level: bit masks of the leaf nodes this lane's ray keeps (0..63 / 64..127).
