@@ -501,12 +501,13 @@ DEV void node_keep(float4 A, float4 B, v2f OX, v2f OY, v2f OZ, v2f DX, v2f DY, v
     v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y};
     v2f R = {__builtin_fabsf(B.z), __builtin_fabsf(B.w)};
     v2f ocx = OX - cx, ocy = OY - cy, ocz = OZ - cz;
-    v2f oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+    // The node test only has to be conservative (its slack is 25 times the rounding of any evaluation
+    // order), so its products and sums are fused: 14 packed instructions instead of 20.
+    v2f oc2 = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx));
     v2f G = {grow, grow}, S = {slack, slack};
     v2f Re = R + G;
-    v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
-    v2f disc = b * b - (oc2 - Re * Re);
-    v2f s = disc + S;
+    v2f b = __builtin_elementwise_fma(ocz, DZ, __builtin_elementwise_fma(ocy, DY, ocx * DX));
+    v2f s = __builtin_elementwise_fma(b, b, S - __builtin_elementwise_fma(-Re, Re, oc2));     // b^2 - (oc2 - Re^2) + slack
     // behind_scale = max(1, a) for rays that may use the shortcut, +inf otherwise
     v2f lim = Re * (v2f){behind_scale, behind_scale};
     const bool behind0 = __builtin_signbitf(B.z) && b.x > lim.x;
