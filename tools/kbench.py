@@ -33,7 +33,7 @@ CONFIGS = {
     **{f"mixed{n}_4k_d4": dict(scene=f"mixed:{n}", w=3840, h=2160, max_depth=4, stack_size=3, shadow_hops=2, golden=None)
        for n in (12, 16, 24, 32, 48, 64, 96, 128)},
     **{f"mixed{n}_4k_d8": dict(scene=f"mixed:{n}", w=3840, h=2160, max_depth=8, stack_size=8, shadow_hops=2, golden=None)
-       for n in (48, 96, 256)},
+       for n in (48, 96, 256, 512)},
     "tori64_4k_d4": dict(scene="tori", w=3840, h=2160, max_depth=4, stack_size=3, shadow_hops=2, golden=None),
     "tori64_4k_d2": dict(scene="tori", w=3840, h=2160, max_depth=2, stack_size=3, shadow_hops=2, golden=None),
     "4k_d8s3_spp4": dict(scene="default", w=3840, h=2160, max_depth=8, stack_size=3, shadow_hops=2, spp_grid=4, golden=None),
