@@ -299,12 +299,12 @@ int hierarchy_min_objects()
 
 // Rays a wave of the persistent hierarchy kernels may have left when it starts tracing them one at a
 // time with all 64 lanes (trace_cooperative: n / 64 rounds of object tests per ray, against one
-// pooled hierarchy trace for all of the wave's rays together; measured best at 2-4 for 256 and for 1024 objects).
+// pooled hierarchy trace for all of the wave's rays together).  Measured: 256 objects best at 2-4
+// (1080p depth 16 -10 % against never); 1024 objects, 16 rounds per ray, lose with any threshold
+// (+7 % at 1, +23 % at 3).
 int coop_rays_for(int n)
 {
-    static_assert(RT_MAX_OBJECTS <= 1024, "the threshold was measured for up to 1024 objects (16 rounds per ray)");
-    (void)n;
-    return 3;
+    return n <= 320 ? 3 : 0;
 }
 
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
