@@ -737,14 +737,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
 #define RT_FLAT_QUOTA 16                           // leaf items a lane contributes per chunk
 #define RT_FLAT_ITEMS (64 * RT_FLAT_QUOTA)
 #define RT_FLAT_CAND 640                            // candidate items: < 64 left over + up to 64 x RT_LEAF new ones per round
-// 1: the top-node loop is pooled as well ((ray, top node) items).  Measured against 0 in one call:
-// 1024 objects 8K 16 spp 1255 -> 1220 ms and 1080p 8.5 -> 8.2 ms, but 64 tori 4K 1.55 -> 1.68 ms and
-// 256 spheres 4K depth 16 327 -> 342 ms (92 items per trace fill 1.4 rounds, the item traffic and 17
-// spilled dwords cost more than the 3 iterations at 29 lanes they replace), so it is off.
-#ifndef RT_FLAT_TOP
-#define RT_FLAT_TOP 0
-#endif
-#define RT_FLAT_RAY_FIELDS (RT_FLAT_TOP ? 9 : 6)     // origin, direction (+ the node-test constants)
+#define RT_FLAT_RAY_FIELDS 6                        // origin, direction
 #define RT_FLAT_DWORDS (RT_FLAT_RAY_FIELDS * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
 static_assert(RT_FLAT_CAND >= 64 + 64 * RT_LEAF, "one round of member tests must fit behind a partial round of candidates");
 
@@ -770,56 +763,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     ray[192 + lane] = dx; ray[256 + lane] = dy; ray[320 + lane] = dz;
     key1[lane] = NOKEY; key2[lane] = NOKEY;
     unsigned long long leaf_lo = 0, leaf_hi = 0;
-#if RT_FLAT_TOP
-    // The leaf nodes under the kept top nodes, pooled like the rest: (ray, top node) items; the
-    // kept leaves are OR-ed into the ray's two mask words, which live in the candidate list's
-    // memory (unused until the leaf rounds).
-    {
-        unsigned long long *lmask = reinterpret_cast<unsigned long long *>(clist);      // [64][2]
-        unsigned int top_mask = 0;
-        NodeTest nt = {0.0f, 0.0f, 0.0f};
-        if (mine) {
-            nt = node_test_constants(L, ox, oy, oz, dot3(dx, dy, dz, dx, dy, dz));
-            top_mask = kept_top_nodes(hl, L, nt, ox, oy, oz, dx, dy, dz);
-        }
-        ray[384 + lane] = nt.grow; ray[448 + lane] = nt.slack; ray[512 + lane] = nt.behind_scale;
-        lmask[2 * lane] = 0ull; lmask[2 * lane + 1] = 0ull;
-        for (;;) {
-            int c = __popc(top_mask);
-            c = c < RT_FLAT_QUOTA ? c : RT_FLAT_QUOTA;
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (total == 0) break;
-            int at = incl - c;
-            for (int k = 0; k < c; ++k) {
-                const int tn = __builtin_ctz(top_mask);
-                top_mask &= top_mask - 1;
-                items[at++] = (unsigned short)((lane << 8) | tn);
-            }
-            for (int base = 0; base < total; base += 64) {
-                HSTAT(HS_TOP);
-                const int j = base + lane;
-                if (j < total) {
-                    const unsigned int it = items[j];
-                    const int r = (int)(it >> 8), tn = (int)(it & 0xffu);
-                    const NodeTest rnt = {ray[384 + r], ray[448 + r], ray[512 + r]};
-                    const unsigned int bits = kept_leaves_under(hl, L, rnt, tn, ray[r], ray[64 + r], ray[128 + r],
-                                                                ray[192 + r], ray[256 + r], ray[320 + r]);
-                    const int first = tn * RT_FAN;
-                    if (bits) atomicOr(&lmask[2 * r + (first >> 6)], (unsigned long long)bits << (first & 63));
-                }
-            }
-        }
-        leaf_lo = lmask[2 * lane]; leaf_hi = lmask[2 * lane + 1];
-    }
-#else
     if (mine) hierarchy_kept_leaves<DEBUG>(hl, L, ox, oy, oz, dx, dy, dz, leaf_lo, leaf_hi, cnt);
-#endif
 
     int ncand = 0;          // wave-uniform: candidate items waiting in clist
     // exact intersections of the waiting candidates, 64 per round; partial rounds only when `all`
