@@ -121,7 +121,7 @@ def main():
     # Multi-GPU runs keep several frames in flight on separate streams; HIP gives a process four
     # hardware queues by default and streams that share a queue do not overlap, so ask for eight
     # (read when the HIP runtime starts, i.e. before torch is imported)
-    if "RANK" in os.environ and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
     import torch
@@ -146,7 +146,7 @@ def main():
     # hardware queues to streams in creation order, and streams created later (after RCCL has
     # made its own) ended up sharing queues, i.e. not overlapping.
     nstreams = int(os.environ.get("RT_BENCH_STREAMS", "4")) if use_dist else 1
-    all_streams = [torch.cuda.Stream(device=dev) for _ in range(max(nstreams, 1))]
+    all_streams = [torch.cuda.Stream(device=dev) for _ in range(max(nstreams, 4))]      # (N = 1 uses the extra ones after the timed region)
     for s_ in all_streams:                      # first use binds a stream to its queue
         with torch.cuda.stream(s_):
             torch.zeros(1, device=dev)
@@ -193,7 +193,7 @@ def main():
     # deepest pixels) overlap the parts of the next frames (RT_BENCH_STREAMS=1 keeps them on one
     # stream, for an A/B).  Four streams only overlap when the process has more than HIP's
     # default of four hardware queues: see the top of main().
-    streams = all_streams if (use_dist and nstreams > 1) else None
+    streams = all_streams[:nstreams] if (use_dist and nstreams > 1) else None
 
     sptrs = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams] if streams else [sptr] * 2
 
@@ -306,6 +306,22 @@ def main():
             result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
             result["gather_only_ms_per_step"] = gather_only_ms                   # transfer alone, max over ranks
             result["part_bytes"] = int(pipe.mine[0].numel())
+
+    # ---- single GPU, informational: the same frames rotating over four streams (what the N > 1 runs
+    # do with their parts): the last waves of a frame, its deepest tiles, overlap the next frames
+    if world == 1 and rank == 0 and not force_gather:
+        k_steps = min(args.steps, 200)
+        bufs = [torch.empty_like(pipe.image) for _ in range(4)]
+        s4 = [ctypes.c_void_p(s_.cuda_stream) for s_ in all_streams[:4]]
+        for i in range(8):
+            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for i in range(k_steps):
+            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
+        torch.cuda.synchronize()
+        result["four_frames_in_flight"] = {"streams": 4, "steps": k_steps, "ms_per_step": (time.perf_counter() - f0) * 1e3 / k_steps,
+                                           "note": "not the reported value: consecutive frames on rotating streams, host clock"}
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
     if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
