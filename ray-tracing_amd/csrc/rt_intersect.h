@@ -711,6 +711,20 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     best_t = bt; best_id = bid;
 }
 
+// Inclusive prefix sum over the 64 lanes in six VALU instructions with DPP operands (shifts inside
+// the rows of 16 lanes, then lane 15 / 31 broadcast into the following rows); lanes without a
+// source add 0.
+DEV int wave_inclusive_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // ------------------------------------------------------------------ the same trace, the wave's work pooled
 //
 // trace_hierarchy above lets every lane walk its own lists, so the wave issues as many member tests
@@ -811,12 +825,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
         // [census: flat_items @ ITER]
         int c = __popcll(leaf_lo) + __popcll(leaf_hi);
         c = c < RT_FLAT_QUOTA ? c : RT_FLAT_QUOTA;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
+        const int incl = wave_inclusive_sum(c);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total == 0) break;
         int at = incl - c;
