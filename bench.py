@@ -48,7 +48,7 @@ WORKLOADS = {
 }
 # 256 CU x 4 SIMD x 32 lanes per clock x 2 (FMA) x 2.4 GHz: a SIMD issues one wave64 v_fma_f32 every
 # 2 cycles; v_pk_fma_f32 takes 4, so packed math reaches the same peak, not twice it
-# (tools/microbench/valu_rate, profiles/r2/valu_issue_rates_mi355x.txt)
+# (tools/microbench/valu_rate; its output is kept with the committed profiles as valu_issue_rates_mi355x.txt)
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 # the same lanes executing one operation per instruction (add, mul; the reference's arithmetic is
 # separately rounded, so the strict flavour cannot fuse): 78.6 T lane-operations/s

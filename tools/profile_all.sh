@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/<tag>/ holds for the headline workload, in one GPU call:
-#   gpurun --timeout 1200 -- 'bash tools/profile_all.sh r2'
+#   gpurun --timeout 1200 -- 'bash tools/profile_all.sh <tag>'
 # then copy gpurun_out/profile_<tag>/ into profiles/<tag>/ (the box's tree does not persist).
 # One profiler pass per run; counters never share a run with tracing.
 TAG=${1:?usage: tools/profile_all.sh <tag>}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other three benchmark workloads, in one GPU call: bench line (with roofline), rocprofv3 kernel
 # stats of the same command, and the counter summary bench.py's executed-work figures come from.
-#   gpurun --timeout 1200 -- 'bash tools/profile_workloads.sh r2'
+#   gpurun --timeout 1200 -- 'bash tools/profile_workloads.sh <tag>'
 # then copy gpurun_out/profile_<tag>/ and gpurun_out/pmc_*.json into profiles/<tag>/.
 TAG=${1:?usage: tools/profile_workloads.sh <tag>}
 OUT=gpurun_out/profile_$TAG
