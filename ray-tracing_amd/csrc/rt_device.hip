@@ -98,6 +98,7 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // magnitude between neighbouring pixels at depth 16, so without this most lanes of a wave
 // wait for its longest pixel.  With kp.whole_tiles the pixels are handed out only when the
 // whole wave is idle: tile after tile with the lanes in lock-step (small scenes).
+// TOPPOOL (with POOL): the loop over the kept top nodes is pooled as well (large hierarchies).
 // POOL (hierarchy kernels): the member tests and exact intersections of a wave's rays are pooled
 // (trace_hierarchy_flat); without it every lane walks its own lists (trace_hierarchy), which has less
 // fixed cost per trace and is what small scenes of cheap objects run.
@@ -125,7 +126,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_WG_ONE 64
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false>
 __global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? (MULTI ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU_HIER1) : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
@@ -220,7 +221,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
     unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3)) + threadIdx.x;
     // pooled hierarchy trace: RT_FLAT_DWORDS of LDS per wave, in the same region
-    float *flat_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) + (threadIdx.x >> 6) * RT_FLAT_DWORDS;
+    float *flat_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) + (threadIdx.x >> 6) * RT_FLAT_DWORDS(TOPPOOL);
     (void)flat_lds;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit
@@ -425,7 +426,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
             }
         }
         if (FLAT && !coop) {
-            trace_hierarchy_flat<DEBUG>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
+            trace_hierarchy_flat<DEBUG, TOPPOOL>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
             coop = true;
         }
         do {
@@ -815,7 +816,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 __global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
@@ -827,11 +828,12 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     static_assert(!REFILL || !DEBUG, "the instrumented kernel keeps one pixel per lane");
     static_assert(!DEEP || (HIER && REFILL && !DEBUG), "the deep-frame code belongs to the persistent hierarchy kernels");
     static_assert(POOL || !DEEP, "deep frames always pool");
-    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL>;
+    static_assert(!TOPPOOL || (POOL && HIER && REFILL && !DEBUG), "the pooled top-node loop is part of the pooled trace");
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL, TOPPOOL>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
-    if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && POOL && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS * 4 : (size_t)RT_QUEUE * 256 * 2);
+    if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && POOL && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS(TOPPOOL) * 4 : (size_t)RT_QUEUE * 256 * 2);
     // at most three workgroups per CU where the host asks for it: more than a quarter of the CU's LDS each
     if (HIER && kp.three_workgroups_per_cu && lds < 41 * 1024) lds = 41 * 1024;
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
@@ -891,16 +893,17 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     // deep frames (the host's choice, see make_kparams): pixels spread over waves + cooperative trace
     const bool deep = kp.coop_rays > 0 || kp.spread_shift < 6;
     const bool pool = kp.pooled_trace != 0;         // (the host's choice as well)
+    const bool toppool = (pool || deep) && kp.pooled_top != 0;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
            : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
-#define RT_LAUNCH_HIER(CAP_, PEND_)                                                                         \
-    (deep ? (multi ? launch_variant<CAP_, false, PEND_, true, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)  \
-                   : launch_variant<CAP_, false, PEND_, false, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)) \
-     : pool ? (multi ? launch_variant<CAP_, false, PEND_, true, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info)        \
-                     : launch_variant<CAP_, false, PEND_, false, true, true>(kp, d_scene, d_out, nullptr, nullptr, s, info))      \
-            : (multi ? launch_variant<CAP_, false, PEND_, true, true, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info)  \
-                     : launch_variant<CAP_, false, PEND_, false, true, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info)))
+#define RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, DEEP_, POOL_, TOP_) \
+    launch_variant<CAP_, false, PEND_, MULTI_, true, true, DEEP_, POOL_, TOP_>(kp, d_scene, d_out, nullptr, nullptr, s, info)
+#define RT_LAUNCH_HIER_M(CAP_, PEND_, MULTI_)                                                              \
+    (deep ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, true, true, true) : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, true, true, false)) \
+     : pool ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, true, true) : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, true, false)) \
+            : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, false, false))
+#define RT_LAUNCH_HIER(CAP_, PEND_) (multi ? RT_LAUNCH_HIER_M(CAP_, PEND_, true) : RT_LAUNCH_HIER_M(CAP_, PEND_, false))
     // Large scenes run as persistent waves with pixel refill (measured 1.1-2.4x there: 64 tori
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
     // 2250 -> 928 ms).  The 5-object scene keeps one pixel per lane: there the lanes' loss of
@@ -936,6 +939,8 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     return RT_LAUNCH(3, false);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_HIER
+#undef RT_LAUNCH_HIER_M
+#undef RT_LAUNCH_HIER_V
 }
 
 int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events, float *d_capture,

@@ -103,6 +103,7 @@ struct KParams {
     int spread_stride;      // are one 8x8 tile); smaller: groups from tiles spread_stride apart in the queue order
     int three_workgroups_per_cu;   // hierarchy kernels: hold the occupancy at 3 waves per SIMD (small deep frames: the
                             // frame waits for its longest waves, which run faster with fewer neighbours)
+    int pooled_top;         // with pooled_trace: pool the loop over the kept top nodes as well (more than 64 leaf nodes)
     int pooled_trace;       // hierarchy kernels: pool the wave's member tests and intersections (trace_hierarchy_flat)
     int coop_rays;          // persistent hierarchy kernels: a wave with at most this many rays left traces them
                             // one at a time with all lanes (0: never)
