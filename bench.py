@@ -73,7 +73,8 @@ def hbm_traffic_bytes(args):
 
 def executed_work(workload, fast_math, kernel_ms):
     """What the hardware executed, from the committed rocprofv3 counter summary of this workload's
-    render kernel (profiles/r*/pmc_<workload>.json, tools/prof_workload.py): VALU lane-operations
+    render kernel (profiles/r*/pmc_<workload>.json, tools/prof_workload.sh; the summary names the kernel
+    sources it was collected with, and one that belongs to other sources is reported as stale): VALU lane-operations
     per launch = SQ_INSTS_VALU x 64 x VALUUtilization (instruction counts do not change from launch
     to launch), their rate over the kernel time measured in this run (launches under the counter
     collection itself run 1.0-1.4x longer) against the 78.6 T lane-operations/s of the chip, VALUBusy
@@ -88,12 +89,19 @@ def executed_work(workload, fast_math, kernel_ms):
         return None
     try:
         c = json.load(open(files[-1]))
+        import rt355
+        fp = rt355.api.library_fingerprint()
+        if c.get("kernel_src_sha256") != fp["kernel_src_sha256"]:
+            # the counters were collected with other kernels than the ones that just ran: no rate
+            return {"stale": True, "source": os.path.relpath(files[-1], ROOT),
+                    "summary_kernel_src_sha256": c.get("kernel_src_sha256"), "running_kernel_src_sha256": fp["kernel_src_sha256"]}
         lane_ops = c["SQ_INSTS_VALU"] * 64.0 * c["VALUUtilization"] / 100.0
         secs = kernel_ms * 1e-3
         return {"valu_lane_ops_per_launch": lane_ops, "rate_T_per_s": lane_ops / secs / 1e12,
                 "frac_of_lane_rate": lane_ops / secs / 1e12 / PEAK_FP32_LANE_OPS_T,
                 "valu_busy_pct": c["VALUBusy"], "valu_utilization_pct": c["VALUUtilization"],
-                "kernel_ms_profiled": c["kernel_ms"], "source": os.path.relpath(files[-1], ROOT)}
+                "kernel_ms_profiled": c["kernel_ms"], "source": os.path.relpath(files[-1], ROOT), "stale": False,
+                "lib_sha256_matches": c.get("lib_sha256") == fp["lib_sha256"]}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -111,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
+    wl_default_stack = wl["stack_size"]
     if args.stack_size is None:
         args.stack_size = wl["stack_size"]
     wl["stack_size"] = args.stack_size
@@ -379,15 +388,23 @@ def main():
             }
 
     if rank == 0:
-        if use_dist:
-            # the gathered + assembled frame must be the frame itself (every N > 1 run checks itself)
-            import hashlib
-            golden = json.load(open(os.path.join(ROOT, "tests", "golden", "default_4k_d8s3.json")))
-            if rehearse_nparts:
-                result["rehearsed_part"] = "0 of %d" % rehearse_nparts
-            elif not args.fast_math and args.stack_size == STACK_SIZE and headline:
-                got = hashlib.sha256(pipe.image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
-                result["gathered_frame_sha_ok"] = got == golden["sha256_rgba8"]
+        # The frame the timed steps left in HBM must be the reference's frame: every run checks itself
+        # against the golden SHA-256 of the workload (llvmpipe fixtures; rows there are bottom-up).
+        import hashlib
+        golden_name = {"default4k": "default_4k_d8s3", "tori64_4k": "tori64_4k_d8s3"}.get(args.workload)
+        golden_file = os.path.join(ROOT, "tests", "golden", "%s.json" % golden_name) if golden_name else None
+        if rehearse_nparts:
+            result["rehearsed_part"] = "0 of %d" % rehearse_nparts
+        elif golden_file and os.path.exists(golden_file) and not args.fast_math and args.stack_size == wl_default_stack:
+            golden = json.load(open(golden_file))
+            torch.cuda.synchronize()
+            got = hashlib.sha256(pipe.image.flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
+            result["frame_sha_ok"] = got == golden["sha256_rgba8"]
+            if use_dist:
+                result["gathered_frame_sha_ok"] = result["frame_sha_ok"]
+        else:
+            result["frame_sha_ok"] = None           # no llvmpipe fixture at this workload's parameters
+        result["library"] = rt355.api.library_fingerprint()
         print(json.dumps(result))
     if use_dist:
         dist.barrier()

@@ -11,7 +11,9 @@
  * main.py:81-84, and raises on link failure, main.py:204-205).
  *
  * Threading: one host thread per process drives the library (the reference is single
- * threaded, main.py:174-178).  Calls are not re-entrant.  One process drives one GPU.
+ * threaded, main.py:174-178).  Calls are not re-entrant.  After rt_init the process drives
+ * one GPU; after rt_init_multi it drives several from the same calls (the library then runs
+ * one issuing thread of its own per additional GPU).
  */
 #ifndef RT355_H
 #define RT355_H
@@ -161,7 +163,11 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
  * RT_NOALLOC_MAX_PENDING pending-ray slots per lane are rejected with RT_E_LIMIT.  All calls on
  * one GPU share that array: the library orders them on the GPU in call order (one host thread, as
  * everywhere in this API); callers that get around that order (several processes cannot: the
- * array is per process) would race on it.                                                 */
+ * array is per process) would race on it.  Under stream capture (hipStreamBeginCapture on
+ * `stream`) the call records its launches into the graph and leaves the library's ordering event
+ * alone: replays of that graph are ordered against other users of the array on the same GPU by
+ * the caller, and every kernel variant a captured call uses must have run once before the capture
+ * (its first launch on a device sets a function attribute).                                */
 #define RT_NOALLOC_MAX_PENDING 4
 #define RT_NOALLOC_WORKGROUPS 1024
 int rt_render_device_noalloc(const rt_params *p, void *d_out, size_t out_bytes, void *stream);

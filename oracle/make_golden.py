@@ -72,6 +72,8 @@ def cases():
         "empty_scene": (lambda: [], dc, 160, 120, 4, 3, 2, "full"),
         "tori64_480": (rt355.tori_stress_scene, rt355.tori_stress_camera(), 480, 270, 8, 3, 2, "full"),
         "tori64_480_d8s8": (rt355.tori_stress_scene, rt355.tori_stress_camera(), 480, 270, 8, 8, 2, "full"),
+        # the 64-tori benchmark configuration at exactly bench.py's parameters (hashes only)
+        "tori64_4k_d8s3": (rt355.tori_stress_scene, rt355.tori_stress_camera(), 3840, 2160, 8, 3, 2, "sha"),
         # llvmpipe stops every shader loop once 65535 loop iterations (all loops of one 8-pixel
         # vector together) have run, so it is only a valid reference while a frame stays under
         # that: deep-stack behaviour is pinned on a 12-sphere cut of the scene.

@@ -106,6 +106,22 @@ def load_library():
     return L
 
 
+def library_fingerprint():
+    """What a measurement must be tied to: SHA-256 of the loaded librt355.so and of the kernel
+    sources it is built from (device code, headers, host side, Makefile).  Counter summaries
+    under profiles/ carry the same two values; a summary whose source hash differs from the
+    running library's describes other kernels."""
+    import hashlib
+    src = hashlib.sha256()
+    csrc = os.path.join(_PKG_DIR, "csrc")
+    for name in ("Makefile", "rt_api.hip", "rt_device.hip", "rt_intersect.h", "rt_numerics.h", "rt_types.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            src.update(name.encode() + b"\0" + f.read())
+    with open(LIB_PATH, "rb") as f:
+        lib = hashlib.sha256(f.read()).hexdigest()
+    return {"lib_sha256": lib, "kernel_src_sha256": src.hexdigest()}
+
+
 def _check(rc):
     if rc != 0:
         raise RtError(rc, _lib.rt_last_error().decode(errors="replace"))

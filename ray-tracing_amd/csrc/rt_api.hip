@@ -311,7 +311,8 @@ int coop_rays_for(int n)
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
 static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && RT_FAN == 8,
               "node masks of trace_hierarchy are sized for this");
-static_assert(RT_MAX_OBJECTS <= 65536, "slot ids and the candidate queue hold 16-bit object indices");
+static_assert(RT_MAX_OBJECTS <= 32768, "slot ids keep the object index in 15 bits (bit 15 flags a sphere)");
+static_assert(RT_MAX_OBJECTS / RT_LEAF <= 128, "the pooled trace's (ray, leaf) items hold the leaf number in 8 bits");
 
 // Effective bounding radius of an object: the square root of the binary32 value br*br the
 // reference's bounding test uses (fragment_shader.glsl:391-402).
@@ -539,7 +540,7 @@ int rt_init(int device)
 {
     if (g.inited) {
         if (device == g.device) return RT_OK;
-        return fail(RT_E_STATE, "already initialised on device %d; one process drives one GPU", g.device);
+        return fail(RT_E_STATE, "already initialised on device %d; call rt_shutdown first (rt_init_multi drives several GPUs)", g.device);
     }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -686,11 +687,13 @@ int rt_set_scene(const rt_object *objs, int n)
     // blocking copy: later launches on any stream see the new scene
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(g.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
+    // from here until every copy is in place there is no current scene: a failure below must not
+    // leave a state in which a retry with the same objects is taken for "unchanged"
+    g.have_scene = false;
+    g.scene_objs.clear();
     g.layout = L;
-    g.have_scene = true;
-    g.scene_objs.assign(objs, objs + n);
     // every device that renders a part holds its own copy of the scene
-    for (auto &pt : g.parts) {
+    auto stage_part = [&](State::Part &pt) -> int {
         HIP_TRY(hipSetDevice(pt.device));
         if (bytes > pt.d_scene_cap) {
             if (pt.d_scene) HIP_TRY(hipFree(pt.d_scene));
@@ -701,9 +704,19 @@ int rt_set_scene(const rt_object *objs, int n)
         }
         HIP_TRY(hipStreamSynchronize(pt.stream));
         HIP_TRY(hipMemcpy(pt.d_scene, blob.data(), bytes, hipMemcpyHostToDevice));
+        return RT_OK;
+    };
+    for (auto &pt : g.parts) {
+        rc = stage_part(pt);
+        if (rc) { (void)hipSetDevice(g.device); return rc; }
     }
     if (!g.parts.empty()) HIP_TRY(hipSetDevice(g.device));
-    if (L.n1 > 0) return ensure_workspace();     // large scenes render as persistent waves
+    if (L.n1 > 0) {                              // large scenes render as persistent waves
+        rc = ensure_workspace();
+        if (rc) return rc;
+    }
+    g.have_scene = true;
+    g.scene_objs.assign(objs, objs + n);
     return RT_OK;
 }
 
@@ -795,8 +808,15 @@ int rt_render_device_noalloc(const rt_params *p, void *d_out, size_t out_bytes, 
     kp.pend_ws_slots = RT_NOALLOC_MAX_PENDING;
     if (kp.resident_workgroups > RT_NOALLOC_WORKGROUPS) kp.resident_workgroups = RT_NOALLOC_WORKGROUPS;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
-    // launches that use the scratch are ordered behind each other on the GPU, whatever their streams
-    const bool shares_scratch = rt_uses_workspace(kp);
+    // launches that use the scratch are ordered behind each other on the GPU, whatever their streams.
+    // Not while `s` is being captured into a graph: waiting there on an event recorded outside the
+    // capture is an error, and an event recorded inside one cannot be waited on by later plain
+    // calls.  A captured call therefore leaves the library's event alone; ordering the graph's
+    // replays against other users of the scratch on this GPU is the caller's job.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(s, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    const bool shares_scratch = rt_uses_workspace(kp) && !capturing;
     if (shares_scratch && g.scratch_busy) HIP_TRY(hipStreamWaitEvent(s, g.scratch_event, 0));
     LaunchInfo info{};
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)

@@ -75,3 +75,75 @@ def test_noalloc_rejects_what_the_array_cannot_hold(gpu_rt):
     # and too small an output buffer, as the allocating entry point does
     p = gpu_rt.api.make_params(gpu_rt.default_camera(), 64, 64)
     assert lib.rt_render_device_noalloc(ctypes.addressof(p), buf.data_ptr(), 100, None) == -6
+
+
+def test_noalloc_two_streams_share_the_scratch_in_order_and_allocate_nothing(gpu_rt):
+    """Two calls of a persistent-wave family back to back on two different streams, different frame
+    sizes, two output buffers: the library's event orders them on the shared array.  Free device
+    memory is the same before and after the calls."""
+    import torch
+    lib = gpu_rt.api.load_library()
+    scene, cam = gpu_rt.mixed_scene(96), gpu_rt.mixed_camera()
+    gpu_rt.set_scene(scene)
+    o = dict(max_depth=5, stack_size=4, shadow_hops=2)
+    sizes = [(648, 360), (203, 117)]
+    params = [gpu_rt.api.make_params(cam, w, h, flags=gpu_rt.api.FLAG_BOTTOM_UP, **o) for w, h in sizes]
+    want, got = [], []
+    for (w, h), p in zip(sizes, params):
+        buf = torch.zeros((w * h * 4,), dtype=torch.uint8, device="cuda:0")
+        assert lib.rt_render_device(ctypes.addressof(p), buf.data_ptr(), buf.numel(), None, 0) == 0, lib.rt_last_error()
+        torch.cuda.synchronize()
+        want.append(buf.cpu().numpy())
+        got.append(torch.full((w * h * 4,), 0xa5, dtype=torch.uint8, device="cuda:0"))
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+    # warm both frames up on their streams (a variant's first launch sets a function attribute, a
+    # stream's first use makes the runtime set up its queue), then measure the calls
+    for p, b, st in zip(params, got, streams):
+        assert lib.rt_render_device_noalloc(ctypes.addressof(p), b.data_ptr(), b.numel(), ctypes.c_void_p(st.cuda_stream)) == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    for b in got:
+        b.fill_(0x5a)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for rep in range(3):
+        for p, b, st in zip(params, got, streams):
+            assert lib.rt_render_device_noalloc(ctypes.addressof(p), b.data_ptr(), b.numel(), ctypes.c_void_p(st.cuda_stream)) == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    for w_, g_ in zip(want, got):
+        assert np.array_equal(w_, g_.cpu().numpy())
+
+
+def test_noalloc_under_graph_capture_replays_the_frame(gpu_rt):
+    """A call of the hierarchy family recorded into a HIP graph (stream capture) and replayed: the
+    replay writes the frame rt_render_device writes, and plain calls keep working afterwards."""
+    import torch
+    lib = gpu_rt.api.load_library()
+    scene, cam = gpu_rt.mixed_scene(96), gpu_rt.mixed_camera()
+    gpu_rt.set_scene(scene)
+    w, h = 320, 200
+    p = gpu_rt.api.make_params(cam, w, h, flags=gpu_rt.api.FLAG_BOTTOM_UP, max_depth=5, stack_size=4, shadow_hops=2)
+    ref = torch.zeros((w * h * 4,), dtype=torch.uint8, device="cuda:0")
+    out = torch.zeros((w * h * 4,), dtype=torch.uint8, device="cuda:0")
+    assert lib.rt_render_device(ctypes.addressof(p), ref.data_ptr(), ref.numel(), None, 0) == 0, lib.rt_last_error()
+    # the variant's first launch on the device happens outside the capture
+    assert lib.rt_render_device_noalloc(ctypes.addressof(p), out.data_ptr(), out.numel(), None) == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.graph(graph, stream=side):
+        rc = lib.rt_render_device_noalloc(ctypes.addressof(p), out.data_ptr(), out.numel(), ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    assert int(out.max()) == 0                      # captured, not executed
+    for _ in range(2):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+    # a plain call after the capture still waits on / records the library's event without error
+    out.zero_()
+    assert lib.rt_render_device_noalloc(ctypes.addressof(p), out.data_ptr(), out.numel(), None) == 0, lib.rt_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())

@@ -33,6 +33,10 @@ for p in ("p1", "p2", "p3"):
     for line in open("$OUT/%s.log" % p):
         if line.startswith("{"):
             out["kernel_ms" if p == "p1" else "kernel_ms_" + p] = json.loads(line)["median_ms"]
+import sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+import rt355
+out.update(rt355.api.library_fingerprint())     # the library these counters belong to
 json.dump(out, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_$WL.json", "w"), indent=1)
 print(json.dumps(out))
 PY
