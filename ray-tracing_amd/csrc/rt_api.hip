@@ -268,6 +268,7 @@ KParams make_kparams(const rt_params *p)
     k.three_workgroups_per_cu = (deep && (long long)p->width * p->height < 4000000ll) ? 1 : 0;
     k.coop_rays = deep ? coop_rays_for(g.layout.n) : 0;
 #ifdef RT_DEV_SWITCHES
+    k.dev_stats = getenv("RT_DEV_STATS") != nullptr;
     if (const char *e = getenv("RT_SPREAD_SHIFT")) k.spread_shift = atoi(e);
     if (const char *e = getenv("RT_COOP_RAYS")) k.coop_rays = atoi(e);
 #endif
@@ -311,7 +312,7 @@ int coop_rays_for(int n)
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
 static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && RT_FAN == 8,
               "node masks of trace_hierarchy are sized for this");
-static_assert(RT_MAX_OBJECTS <= 32768, "slot ids keep the object index in 15 bits (bit 15 flags a sphere)");
+static_assert(RT_MAX_OBJECTS <= 32768, "slot ids keep the object index in 15 bits (bit 15 flags a torus)");
 static_assert(RT_MAX_OBJECTS / RT_LEAF <= 128, "the pooled trace's (ray, leaf) items hold the leaf number in 8 bits");
 
 // Effective bounding radius of an object: the square root of the binary32 value br*br the
@@ -440,8 +441,8 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
         if (sl < n) {
             const float *src = blob + 8 * (idx[sl] >> 1) + (idx[sl] & 1);   // the object's own bound record
             r[0] = src[0]; r[2] = src[2]; r[4] = src[4]; r[6] = src[6];
-            // bit 15: the object is a sphere (indices are below 1024)
-            slot_id[sl] = (uint16_t)(idx[sl] | (objs[idx[sl]].type == 1 ? 0x8000 : 0));
+            // bit 15: the object is a torus (indices are below 1024)
+            slot_id[sl] = (uint16_t)(idx[sl] | (objs[idx[sl]].type == 1 ? 0 : 0x8000));
         } else {
             r[0] = r[2] = r[4] = 0.0f; r[6] = -INFINITY;
             slot_id[sl] = 0;

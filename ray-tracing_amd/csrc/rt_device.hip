@@ -428,6 +428,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         if (FLAT && !coop) {
             trace_hierarchy_flat<DEBUG, TOPPOOL>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
             coop = true;
+#ifdef RT_DEV_SWITCHES
+            if (kp.wave_log && kp.dev_stats && active)
+                dev_trace_stats<DEBUG>(sc, lds, L, ox, oy, oz, dx, dy, dz, id_coop >= 0 && id_coop < L.n ? t_coop : 1e30f,
+                                       state == ST_SHADOW, light_dist - travelled, cnt);
+#endif
         }
         do {
         if (REFILL && !active) break;

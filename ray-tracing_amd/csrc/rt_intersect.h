@@ -12,7 +12,11 @@ namespace RT_NS {
 // Two uses of the same LDS counter array in the instrumented flavour: event counts (one per
 // lane and event, the FLOP accounting), or -- wave_mode -- a profile of the code blocks a wave
 // executes (WCNT: once per wave that enters the block with any lane; LCNT: lanes in it).
-enum { HS_TOP, HS_LEAF, HS_CAND, HS_SCAN, HS_COOP_RAY, HS_COOP_ROUND, HS_COUNT };
+enum { HS_TOP, HS_LEAF, HS_CAND, HS_SCAN, HS_COOP_RAY, HS_COOP_ROUND,
+       // development statistics of the pooled trace (lane sums only)
+       HS_RAYS, HS_RAYS_SHADOW, HS_RAYS_HIT, HS_KEPT, HS_KEPT_NEEDED, HS_KEPT_SHADOW_NEEDED, HS_CANDS, HS_CANDS_NEEDED,
+       HS_TORUS_ROUND, HS_RAYS_NEAR_HIT,
+       HS_COUNT };
 template <bool DEBUG> struct Counters {
     unsigned int *lds_ev;
     DEV void add(int) const {}
@@ -27,6 +31,7 @@ template <bool DEBUG> struct Counters {
         hs_lane[k]++;
         if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) hs_wave[k]++;
     }
+    DEV void hadd(int k, unsigned int n) const { hs_lane[k] += n; }
 #else
     DEV void hstat(int) const {}
 #endif
@@ -660,14 +665,14 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             // (spheres that lie behind the ray are left out, see above)
             if (!(disc.x < 0.0f)) {
                 const unsigned int sid = slot_id[2 * mp];
-                if (!((sid & 0x8000u) && b.x > 0.0f && b.x < 1e15f && c.x >= 0.0f)) {
+                if (!(!(sid & 0x8000u) && b.x > 0.0f && b.x < 1e15f && c.x >= 0.0f)) {
                     if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
                     count++;
                 }
             }
             if (!(disc.y < 0.0f)) {
                 const unsigned int sid = slot_id[2 * mp + 1];
-                if (!((sid & 0x8000u) && b.y > 0.0f && b.y < 1e15f && c.y >= 0.0f)) {
+                if (!(!(sid & 0x8000u) && b.y > 0.0f && b.y < 1e15f && c.y >= 0.0f)) {
                     if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
                     count++;
                 }
@@ -711,6 +716,14 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     best_t = bt; best_id = bid;
 }
 
+// The wave's mask of lanes in which `p` holds (the compare's own result, no detour through a 0/1
+// value), and a lane's rank among the lanes of a mask that lie below it.
+DEV unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DEV int rank_in_mask(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
 // Inclusive prefix sum over the 64 lanes in six VALU instructions with DPP operands (shifts inside
 // the rows of 16 lanes, then lane 15 / 31 broadcast into the following rows); lanes without a
 // source add 0.
@@ -750,11 +763,11 @@ DEV int wave_inclusive_sum(int x)
 // lanes that hold a ray.  wl = this wave's RT_FLAT_DWORDS dwords of LDS.
 #define RT_FLAT_QUOTA 16                           // leaf items a lane contributes per chunk
 #define RT_FLAT_ITEMS (64 * RT_FLAT_QUOTA)
-#define RT_FLAT_CAND 640                            // candidate items: < 64 left over + up to 64 x RT_LEAF new ones per round
+#define RT_FLAT_CAND 640                            // candidate items: < 64 + < 64 left over (mixed stack, tori stack) + up to 64 x RT_LEAF new ones per round
 // ray table: origin, direction; with the pooled top-node loop also grow, slack and behind limit of the node test
 #define RT_FLAT_RAY_FIELDS(toppool) ((toppool) ? 9 : 6)
 #define RT_FLAT_DWORDS(toppool) (RT_FLAT_RAY_FIELDS(toppool) * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
-static_assert(RT_FLAT_CAND >= 64 + 64 * RT_LEAF, "one round of member tests must fit behind a partial round of candidates");
+static_assert(RT_FLAT_CAND >= 2 * 64 + 64 * RT_LEAF, "one round of member tests must fit next to a partial round of candidates of either kind");
 
 template <bool DEBUG, bool TOPPOOL>
 DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayout &L, int polish, float *wl, bool mine,
@@ -827,47 +840,68 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
         leaf_lo = lmask[2 * lane]; leaf_hi = lmask[2 * lane + 1];
     }
 
-    int ncand = 0;          // wave-uniform: candidate items waiting in clist
-    // exact intersections of the waiting candidates, 64 per round; partial rounds only when `all`
+    // Candidate items.  clist is one array used from both ends: the items the leaf rounds append
+    // (spheres and tori mixed) are a stack that grows upwards from clist[0]; the exact rounds take
+    // them off its top 64 at a time, intersect the spheres among them at once and move the tori to
+    // a second stack that grows downwards from clist[RT_FLAT_CAND - 1], so that the quartic solve
+    // (about seven times the instructions of the sphere's quadratic) runs in rounds of its own with
+    // all lanes on tori instead of in every round with the few lanes that happen to hold one.  An
+    // item moved to the second stack has just left the first, so both always fit: fewer than 64 of
+    // each wait when a leaf round starts, which appends at most 64 x RT_LEAF.
+    int ncand = 0, ntor = 0;          // wave-uniform: items on the mixed stack / on the tori stack
+    auto offer_hit = [&](int r, int i, float t, bool hit) {
+        if (hit && t < 1e30f) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)i;
+            const unsigned long long old = atomicMin(&key1[r], key);
+            const unsigned long long loser = old > key ? old : key;
+            if (loser != NOKEY) atomicMin(&key2[r], loser);
+        }
+    };
+    // bounding-test terms of object i for ray r, as the reference computes them (:399-402), and the exact intersection
+    auto exact_item = [&](unsigned int it, bool torus) {
+        const int r = (int)(it >> 16), i = (int)(it & 0x7fffu);
+        const float rox = ray[r], roy = ray[64 + r], roz = ray[128 + r];
+        const float rdx = ray[192 + r], rdy = ray[256 + r], rdz = ray[320 + r];
+        const float a = dot3(rdx, rdy, rdz, rdx, rdy, rdz);
+        const float *rec = sc + 8 * (i >> 1) + (i & 1);
+        const float ocx = rox - rec[0], ocy = roy - rec[2], ocz = roz - rec[4];
+        const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+        const float c = oc2 - rec[6];
+        const float b = (ocz * rdz + ocy * rdy) + ocx * rdx;
+        float t; bool hit;
+        int kd = -1;
+        if (torus) { kd = kind[i]; kd = kd < 0 ? 0 : kd; }
+        candidate_exact<DEBUG>(sc, L, polish, torus ? kd : -1, a, ocx, ocy, ocz, b, c, rdx, rdy, rdz, t, hit, cnt);
+        offer_hit(r, i, t, hit);
+    };
+    // full rounds while 64 items wait; with `all` also the partial last ones
     auto exact_rounds = [&](bool all) {
-        int done = 0;
-        while (ncand - done >= (all ? 1 : 64)) {
+        while (ncand >= 64 || (all && ncand > 0)) {
             // [census: flat_exact_round @ FLAT_EXACT]
             HSTAT(HS_CAND);
-            const int j = done + lane;
-            if (j < ncand) {
-                const unsigned int it = clist[j];
-                const int r = (int)(it >> 16), i = (int)(it & 0xffffu);
-                const float rox = ray[r], roy = ray[64 + r], roz = ray[128 + r];
-                const float rdx = ray[192 + r], rdy = ray[256 + r], rdz = ray[320 + r];
-                const float a = dot3(rdx, rdy, rdz, rdx, rdy, rdz);
-                const float *rec = sc + 8 * (i >> 1) + (i & 1);
-                const float ocx = rox - rec[0], ocy = roy - rec[2], ocz = roz - rec[4];
-                const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-                const float c = oc2 - rec[6];
-                const float b = (ocz * rdz + ocy * rdy) + ocx * rdx;
-                float t; bool hit;
-                candidate_exact<DEBUG>(sc, L, polish, kind[i], a, ocx, ocy, ocz, b, c, rdx, rdy, rdz, t, hit, cnt);
-                if (hit && t < 1e30f) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)i;
-                    const unsigned long long old = atomicMin(&key1[r], key);
-                    const unsigned long long loser = old > key ? old : key;
-                    if (loser != NOKEY) atomicMin(&key2[r], loser);
-                }
+            const int first = ncand >= 64 ? ncand - 64 : 0;
+            const int j = first + lane;
+            const bool have = j < ncand;
+            const unsigned int it = clist[have ? j : 0];
+            const bool is_torus = have && (it & 0x8000u);
+            const unsigned long long mt = wave_mask(is_torus);
+            if (mt != 0ull) {
+                if (is_torus) clist[RT_FLAT_CAND - 1 - (ntor + rank_in_mask(mt))] = it;
+                ntor += __popcll(mt);
             }
-            done += 64;
+            if (have && !is_torus) exact_item(it, false);
+            ncand = first;
         }
-        // what is left (less than a round) moves to the front
-        // [census: flat_exact_compact @ ITER]
-        const int rem = ncand - done;
-        if (rem > 0) {
-            unsigned int v = 0;
-            if (lane < rem) v = clist[done + lane];
-            if (lane < rem) clist[lane] = v;
+        while (ntor >= 64 || (all && ntor > 0)) {
+            // [census: flat_torus_round @ FLAT_TORUS]
+            HSTAT(HS_TORUS_ROUND);
+            const int take = ntor >= 64 ? 64 : ntor;
+            if (lane < take) exact_item(clist[RT_FLAT_CAND - ntor + lane], true);
+            ntor -= take;
         }
-        ncand = rem > 0 ? rem : 0;
     };
 
+    const unsigned int *slot_pair = reinterpret_cast<const unsigned int *>(slot_id);     // the ids of slots 2k, 2k + 1
     for (;;) {
         // this chunk's items: up to RT_FLAT_QUOTA kept leaves per lane, at the lane's offset in the wave's list
         // [census: flat_items @ ITER]
@@ -894,6 +928,9 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             const float rdx = ray[192 + r], rdy = ray[256 + r], rdz = ray[320 + r];
             const v2f OX = {rox, rox}, OY = {roy, roy}, OZ = {roz, roz};
             const v2f DX = {rdx, rdx}, DY = {rdy, rdy}, DZ = {rdz, rdz};
+            const unsigned int entry_hi = (unsigned int)r << 16;
+            // lanes without an item never pass: their "behind" word has no sign bit whatever the member
+            const unsigned int live = have ? 0xffffffffu : 0x7fffffffu;
 #pragma unroll
             for (int m = 0; m < RT_LEAF / 2; ++m) {
                 const int mp = leaf * (RT_LEAF / 2) + m;
@@ -905,17 +942,24 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
                 v2f cc = oc2 - br2;
                 v2f b = (ocz * DZ + ocy * DY) + ocx * DX;
                 v2f disc = b * b - cc;
-                const unsigned int sid0 = slot_id[2 * mp], sid1 = slot_id[2 * mp + 1];
-                const bool p0 = have && !(disc.x < 0.0f) && !((sid0 & 0x8000u) && b.x > 0.0f && b.x < 1e15f && cc.x >= 0.0f);
-                const bool p1 = have && !(disc.y < 0.0f) && !((sid1 & 0x8000u) && b.y > 0.0f && b.y < 1e15f && cc.y >= 0.0f);
-                const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (p0) clist[ncand + __popcll(m0 & below)] = ((unsigned int)r << 16) | (sid0 & 0x7fffu);
+                // A sphere behind the ray (b > 0, c >= 0, see trace_hierarchy) is left out.  In one word: the
+                // sign bits of b and of c and the torus flag of the slot id (bit 15 of each half) or-ed; the
+                // member can be a candidate only if the result is negative.  That also leaves out spheres with
+                // b = +0 (then disc >= 0 needs c <= 0, and c = +0 gives both roots 0: no hit), with b >= 1e15
+                // (the only hit such a sphere can report is t = inf, which never beats 1e30) and with a NaN of
+                // positive sign in b or c (the sphere's solve then yields NaN: no hit).
+                const unsigned int sp = slot_pair[mp];
+                const unsigned int k0 = (__float_as_uint(b.x) | __float_as_uint(cc.x) | (sp << 16)) & live;
+                const unsigned int k1 = (__float_as_uint(b.y) | __float_as_uint(cc.y) | sp) & live;
+                const bool p0 = !(disc.x < 0.0f) && (int)k0 < 0;
+                const bool p1 = !(disc.y < 0.0f) && (int)k1 < 0;
+                const unsigned long long m0 = wave_mask(p0), m1 = wave_mask(p1);
+                if (p0) clist[ncand + rank_in_mask(m0)] = entry_hi | (sp & 0xffffu);
                 ncand += __popcll(m0);
-                if (p1) clist[ncand + __popcll(m1 & below)] = ((unsigned int)r << 16) | (sid1 & 0x7fffu);
+                if (p1) clist[ncand + rank_in_mask(m1)] = entry_hi | (sp >> 16);
                 ncand += __popcll(m1);
             }
-            if (ncand > RT_FLAT_CAND - 64 * RT_LEAF) exact_rounds(false);
+            if (ncand + ntor > RT_FLAT_CAND - 64 * RT_LEAF) exact_rounds(false);
         }
     }
     exact_rounds(true);
@@ -967,6 +1011,67 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
         best_t = bt; best_id = bid;
     }
 }
+
+#ifdef RT_DEV_SWITCHES
+// Development statistics: what a distance cut-off could save.  For a ray whose trace returned t_final
+// (1e30: nothing hit), counts its kept leaf nodes, those whose entry distance lies in front of the hit
+// (the only ones an ordered walk with a cut-off would have to open), the members that pass the
+// bounding test and those among them whose t_bound lies in front of the hit; for shadow rays the same
+// against the distance that is left to the light.
+template <bool DEBUG>
+DEV void dev_trace_stats(const float *sc, const float *hl, const SceneLayout &L,
+                         float ox, float oy, float oz, float dx, float dy, float dz,
+                         float t_final, bool shadow, float light_left, const Counters<DEBUG> &cnt)
+{
+    if constexpr (!DEBUG) {
+        unsigned long long lo, hi;
+        hierarchy_kept_leaves<DEBUG>(hl, L, ox, oy, oz, dx, dy, dz, lo, hi, cnt);
+        const float a = dot3(dx, dy, dz, dx, dy, dz);
+        const NodeTest nt = node_test_constants(L, ox, oy, oz, a);
+        const float *leafn = hl + (L.off_leaf - L.off_top);
+        const float4 *memb = reinterpret_cast<const float4 *>(hl + (L.off_member - L.off_top));
+        const unsigned short *slot_id = reinterpret_cast<const unsigned short *>(hl + (L.off_slot_id - L.off_top));
+        cnt.hadd(HS_RAYS, 1);
+        if (shadow) cnt.hadd(HS_RAYS_SHADOW, 1);
+        if (t_final < 1e30f) cnt.hadd(HS_RAYS_HIT, 1);
+        if (t_final < 1.0f) cnt.hadd(HS_RAYS_NEAR_HIT, 1);
+        const float cut = t_final + 4.0f * nt.grow;
+        float first_lb = 1e30f;
+        int needed = 0;
+        while (lo | hi) {
+            int leaf;
+            if (lo) { leaf = __builtin_ctzll(lo); lo &= lo - 1; }
+            else { leaf = 64 + __builtin_ctzll(hi); hi &= hi - 1; }
+            const float *p = leafn + 8 * (leaf >> 1) + (leaf & 1);
+            const float ocx = ox - p[0], ocy = oy - p[2], ocz = oz - p[4], Re = __builtin_fabsf(p[6]) + nt.grow;
+            const float b = ocz * dz + ocy * dy + ocx * dx;
+            const float sdisc = b * b - ((ocz * ocz + ocy * ocy + ocx * ocx) - Re * Re) + nt.slack;
+            const float lb = -b - __builtin_amdgcn_sqrtf(sdisc > 0.0f ? sdisc : 0.0f) - nt.grow;
+            cnt.hadd(HS_KEPT, 1);
+            const bool need = !(lb > cut);
+            if (need) { cnt.hadd(HS_KEPT_NEEDED, 1); needed++; }
+            if (shadow && !(lb > cut) && !(lb > light_left + 4.0f * nt.grow)) cnt.hadd(HS_KEPT_SHADOW_NEEDED, 1);
+            else if (!shadow && need) cnt.hadd(HS_KEPT_SHADOW_NEEDED, 1);
+            first_lb = lb < first_lb ? lb : first_lb;
+            for (int m = 0; m < RT_LEAF; ++m) {
+                const int sl = leaf * RT_LEAF + m;
+                const float *q = reinterpret_cast<const float *>(memb) + 8 * (sl >> 1) + (sl & 1);
+                const float mx = ox - q[0], my = oy - q[2], mz = oz - q[4];
+                const float c = ((mz * mz + my * my) + mx * mx) - q[6];
+                const float bb = (mz * dz + my * dy) + mx * dx;
+                const float disc = bb * bb - c;
+                const unsigned int sid = slot_id[sl];
+                if (!(disc < 0.0f) && !(!(sid & 0x8000u) && bb > 0.0f && bb < 1e15f && c >= 0.0f)) {
+                    cnt.hadd(HS_CANDS, 1);
+                    const float tb = -bb - __builtin_amdgcn_sqrtf(disc);
+                    if (!(tb > cut)) cnt.hadd(HS_CANDS_NEEDED, 1);
+                }
+            }
+        }
+        (void)first_lb; (void)needed; (void)sc;
+    }
+}
+#endif
 
 // ------------------------------------------------------------------ one ray at a time, the whole wave on it
 //

@@ -108,6 +108,7 @@ struct KParams {
     int coop_rays;          // persistent hierarchy kernels: a wave with at most this many rays left traces them
                             // one at a time with all lanes (0: never)
 #ifdef RT_DEV_SWITCHES
+    int dev_stats;                  // development builds: collect the cut-off statistics of the pooled trace (slow)
     unsigned long long *wave_log;   // development builds: per persistent wave {start, end (100 MHz ticks), loop trips, pixels,
                                     // hierarchy-walk loop iterations per wave [6] and per lane [6]}, RT_WAVE_LOG_WORDS words
 #endif
@@ -125,7 +126,7 @@ enum RtEvent {
     EV_REFR_TRY, EV_REFR_PUSH, EV_REFL_EVAL, EV_REFL_PUSH, EV_DROP,
     EV_COUNT
 };
-#define RT_WAVE_LOG_WORDS 16
+#define RT_WAVE_LOG_WORDS 48
 #define RT_COUNTER_SLOTS 64      // counters the instrumented kernel keeps (events, or the wave profile's blocks)
 static_assert(EV_COUNT <= RT_COUNTER_SLOTS, "event counters");
 

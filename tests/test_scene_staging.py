@@ -61,9 +61,9 @@ def test_hierarchy_invariants(rt, which, n):
     memb, _ = bound_records(blob, L["n1"] * leaf, L["off_member"])
     raw_ids = blob[L["off_slot_id"]:L["off_slot_id"] + L["n1"] * leaf // 2].view(np.uint16)
     ids = raw_ids & 0x7fff
-    # bit 15 of a slot id marks a sphere; a node of spheres only stores its radius negated
+    # bit 15 of a slot id marks a torus; a node of spheres only stores its radius negated
     is_sphere = np.array([o["type"] == 1 for o in scene])
-    assert np.array_equal((raw_ids[:n] & 0x8000) != 0, is_sphere[ids[:n]])
+    assert np.array_equal((raw_ids[:n] & 0x8000) == 0, is_sphere[ids[:n]])
     for nodes, span in ((leafn, leaf), (top, leaf * fan)):
         for j in range(len(nodes)):
             members = ids[j * span:min(n, (j + 1) * span)]
