@@ -313,7 +313,7 @@ int coop_rays_for(int n)
 static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && RT_FAN == 8,
               "node masks of trace_hierarchy are sized for this");
 static_assert(RT_MAX_OBJECTS <= 32768, "slot ids keep the object index in 15 bits (bit 15 flags a torus)");
-static_assert(RT_MAX_OBJECTS / RT_LEAF <= 128, "the pooled trace's (ray, leaf) items hold the leaf number in 8 bits");
+static_assert(RT_MAX_OBJECTS / RT_LEAF + 1 <= 256, "the pooled trace's (ray, leaf) items hold the leaf number, or that of the empty leaf behind the last one, in 8 bits");
 
 // Effective bounding radius of an object: the square root of the binary32 value br*br the
 // reference's bounding test uses (fragment_shader.glsl:391-402).
@@ -436,7 +436,7 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
     L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
     L.hR = std::nextafter((float)reach, INFINITY);
     uint16_t *slot_id = reinterpret_cast<uint16_t *>(blob + L.off_slot_id);
-    for (int sl = 0; sl < L.n1 * RT_LEAF; ++sl) {
+    for (int sl = 0; sl < (L.n1 + 1) * RT_LEAF; ++sl) {
         float *r = blob + L.off_member + 8 * (sl >> 1) + (sl & 1);
         if (sl < n) {
             const float *src = blob + 8 * (idx[sl] >> 1) + (idx[sl] & 1);   // the object's own bound record

@@ -221,7 +221,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     // candidate queue of the hierarchy walk: [entry][thread], 16 bits each (never together with LDSP)
     unsigned short *queue = reinterpret_cast<unsigned short *>(lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3)) + threadIdx.x;
     // pooled hierarchy trace: RT_FLAT_DWORDS of LDS per wave, in the same region
-    float *flat_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) + (threadIdx.x >> 6) * RT_FLAT_DWORDS(TOPPOOL);
+    // (the wave number through readfirstlane: the compiler then keeps the wave's LDS base in a scalar register)
+    float *flat_lds = lds + ((lds_dwords + (DEBUG ? RT_COUNTER_SLOTS : 0) + 3) & ~3) +
+                      __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * RT_FLAT_DWORDS(TOPPOOL);
     (void)flat_lds;
     int state = ST_PATH;
     // shading context carried across the shadow hops of one hit

@@ -17,9 +17,9 @@
 // top node RT_FAN consecutive leaf nodes):
 //   [.., + 8*ceil(n2/2)) top[j]      = { cx0 cx1 cy0 cy1 } { cz0 cz1 R0 R1 }: nodes 2j, 2j+1
 //   [.., + 8*ceil(n1/2)) leaf[j]     = same record, leaf nodes 2j, 2j+1
-//   [.., + 8*n1*RT_LEAF/2) member[s] = bound records (as bound[]) of the objects in slot order;
-//                                      empty slots carry br = -inf
-//   [.., + n1*RT_LEAF/2) slot_id[s]  = object index of slot s, 16 bits each
+//   [.., + 8*(n1+1)*RT_LEAF/2) member[s] = bound records (as bound[]) of the objects in slot order;
+//                                      empty slots carry br = -inf; the slots of leaf n1 are all empty
+//   [.., + (n1+1)*RT_LEAF/2) slot_id[s] = object index of slot s, 16 bits each; bit 15: the object is a torus
 // Keeping only the 16 bytes per object of the bound record in the per-object hot loop and
 // everything else behind the bound test is what makes 1024 objects fit in LDS next to
 // several workgroups.
@@ -62,8 +62,9 @@ static inline SceneLayout scene_layout(int n, int ntori, bool hierarchy)
         L.off_top = end;
         L.off_leaf = L.off_top + 8 * ((L.n2 + 1) / 2);
         L.off_member = L.off_leaf + 8 * ((L.n1 + 1) / 2);
-        L.off_slot_id = L.off_member + 8 * (L.n1 * RT_LEAF / 2);
-        end = (L.off_slot_id + L.n1 * RT_LEAF / 2 + 3) & ~3;
+        // one leaf more than there are leaf nodes: empty slots only (what a lane without work tests)
+        L.off_slot_id = L.off_member + 8 * ((L.n1 + 1) * RT_LEAF / 2);
+        end = (L.off_slot_id + (L.n1 + 1) * RT_LEAF / 2 + 3) & ~3;
     }
     L.total_dwords = end;
     return L;
