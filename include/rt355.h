@@ -71,9 +71,15 @@ enum {
     RT_FLAG_NO_ACCEL      = 1u << 4,  /* always run the plain per-object loop of the reference, also
                                          on large scenes (the sphere-hierarchy traversal used there
                                          returns the same hits; this flag exists to verify that)   */
-    RT_FLAG_OUT_RGB8      = 1u << 5   /* write packed RGB8, 3 bytes per pixel (the reference's alpha
+    RT_FLAG_OUT_RGB8      = 1u << 5,  /* write packed RGB8, 3 bytes per pixel (the reference's alpha
                                          is the constant 1.0, fragment_shader.glsl:674): a quarter
                                          less to move between GPUs and to the host; not with OUT_F32 */
+    RT_FLAG_PIXEL_ORDER   = 1u << 6   /* deep frames of large scenes (max_depth >= 12 with 8 or more
+                                         pending rays): a short pilot launch ranks the pixels by the
+                                         size of their ray trees and the frame is rendered costliest
+                                         pixels first.  The library does this by itself when the frame
+                                         has many pixels per GPU lane; the flag forces it at any size
+                                         (the frame is the same: this exists to verify that)        */
 };
 
 /* The uniforms of fragment_shader.glsl:12-15 as main.py:277-280 sets them, plus the

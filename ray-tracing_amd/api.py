@@ -28,6 +28,7 @@ FLAG_BOTTOM_UP = 1 << 2
 FLAG_OUT_F32 = 1 << 3
 FLAG_NO_ACCEL = 1 << 4
 FLAG_OUT_RGB8 = 1 << 5
+FLAG_PIXEL_ORDER = 1 << 6
 
 
 class RtError(RuntimeError):
@@ -259,10 +260,11 @@ def make_params(camera, w, h, *, max_depth=4, stack_size=3, shadow_hops=2, spp_g
     return p
 
 
-def _flags(fast_math, newton_polish, bottom_up, out_f32, no_accel=False, out_rgb8=False):
+def _flags(fast_math, newton_polish, bottom_up, out_f32, no_accel=False, out_rgb8=False, pixel_order=False):
     return ((FLAG_FAST_MATH if fast_math else 0) | (FLAG_NEWTON_POLISH if newton_polish else 0) |
             (FLAG_BOTTOM_UP if bottom_up else 0) | (FLAG_OUT_F32 if out_f32 else 0) |
-            (FLAG_NO_ACCEL if no_accel else 0) | (FLAG_OUT_RGB8 if out_rgb8 else 0))
+            (FLAG_NO_ACCEL if no_accel else 0) | (FLAG_OUT_RGB8 if out_rgb8 else 0) |
+            (FLAG_PIXEL_ORDER if pixel_order else 0))
 
 
 def set_scene(scene):
@@ -273,12 +275,12 @@ def set_scene(scene):
 
 def _render_host(scene, camera, w, h, channels, *, max_depth=4, stack_size=3, shadow_hops=2, spp_grid=1,
                  fast_math=False, newton_polish=False, bottom_up=False, out_f32=False, part=0, nparts=1,
-                 no_accel=False, light_grid=1, light_size=0.0, out=None):
+                 no_accel=False, light_grid=1, light_size=0.0, out=None, pixel_order=False):
     L = _ensure_init()
     arr = pack_scene(scene)
     p = make_params(camera, w, h, max_depth=max_depth, stack_size=stack_size, shadow_hops=shadow_hops,
                     spp_grid=spp_grid,
-                    flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel, out_rgb8=channels == 3),
+                    flags=_flags(fast_math, newton_polish, bottom_up, out_f32, no_accel, out_rgb8=channels == 3, pixel_order=pixel_order),
                     part=part, nparts=nparts, light_grid=light_grid, light_size=light_size)
     nbytes = L.rt_output_bytes(ctypes.addressof(p))
     bpp = 16 if out_f32 else channels
@@ -298,7 +300,8 @@ def render_rgba(scene, camera, w, h, **opts):
     unless bottom_up (GL read-back order).  With nparts > 1 only this part's bands.
     opts: max_depth, stack_size, shadow_hops, spp_grid, fast_math, newton_polish, bottom_up,
     out_f32, part, nparts, no_accel, light_grid, light_size (G x G samples of a square area light
-    of that edge; 1 = the reference's point light)."""
+    of that edge; 1 = the reference's point light), pixel_order (deep frames: force the pilot launch and
+    the cost order of the pixels at any frame size; the frame is the same)."""
     return _render_host(scene, camera, w, h, 4, **opts)
 
 

@@ -52,6 +52,11 @@ struct State {
     float *d_pend_ws = nullptr;         // pending-ray workspace of the persistent-wave kernels
     hipEvent_t ws_event = nullptr;      // end of the last launch that used the workspace
     bool ws_busy = false;
+    // deep frames: ray counts of the pilot launch (one byte per 2x2 pixel cell), the cells sorted by
+    // them, and the 2 x 256 counters of the sort (see KParams::pilot_cost)
+    unsigned char *d_pilot_cost = nullptr;
+    unsigned int *d_order = nullptr, *d_order_counters = nullptr;
+    size_t order_cap = 0;               // cells the three buffers hold
 #ifdef RT_DEV_SWITCHES
     unsigned long long *d_wave_log = nullptr;   // RT_WAVE_LOG_WORDS words per resident wave (development builds)
 #endif
@@ -263,6 +268,8 @@ KParams make_kparams(const rt_params *p)
     // iterations with 21 lanes).
     k.pooled_trace = (deep || g.layout.n >= 192 || g.layout.ntori >= 48) ? 1 : 0;
     k.pooled_top = (k.pooled_trace && g.layout.n1 > 64) ? 1 : 0;     // measured: 1024 objects -4 to -6 %, 512 objects +11 %
+    k.deep = deep ? 1 : 0;
+    k.cells_x = (p->width + 1) / 2;
     k.spread_shift = deep ? 0 : 6;
     // measured with four waves per SIMD: 256 spheres depth 16 at 1080p 136 -> 146 ms, at 4K 351 -> 332 ms
     k.three_workgroups_per_cu = (deep && (long long)p->width * p->height < 4000000ll) ? 1 : 0;
@@ -471,6 +478,107 @@ const int k_event_flops[EV_COUNT] = {
     8, 73, 39, 1, 11, 7,     // phong shadowed / full :490-513; attenuation :443-448, :457, :462-468, :473-474
     28, 16, 3, 21, 0};       // refraction :613-620; reflection :629-637; drops
 
+// ---- deep frames: the order in which the render launch hands out its pixels (see KParams::pilot_cost)
+// Counting sort of the cells by the pilot's ray count, largest first: histogram, exclusive scan from the
+// top, scatter (inside one count the order is whatever the atomics make of it; the frame does not
+// depend on the order of its pixels).
+__global__ void order_hist_kernel(const unsigned char *__restrict__ cost, int ncells, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ncells; i += gridDim.x * 256) atomicAdd(&h[cost[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void order_scan_kernel(const unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    unsigned int above = 0u;                                     // cells with a larger count come first
+    for (int c = 255; c > (int)threadIdx.x; --c) above += h[c];
+    cursor[threadIdx.x] = above;
+}
+__global__ void order_scatter_kernel(const unsigned char *__restrict__ cost, int ncells, int cells_x,
+                                     unsigned int *__restrict__ cursor, unsigned int *__restrict__ order)
+{
+    __shared__ unsigned int h[256], base[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned int c = 0u, rank = 0u;
+    if (i < ncells) { c = cost[i]; rank = atomicAdd(&h[c], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < ncells) order[base[c] + rank] = ((unsigned int)(i / cells_x) << 16) | (unsigned int)(i % cells_x);
+}
+
+// Depth of the pilot's ray trees.  The pixels whose trees are deep at the frame's depth are those whose
+// first few segments keep hitting glass, which this depth already shows.
+int pilot_depth()
+{
+#ifdef RT_DEV_SWITCHES
+    if (const char *e = getenv("RT_PILOT_DEPTH")) return atoi(e);
+#endif
+    return 6;
+}
+
+// Pilot launch + sort for a deep frame: fills kp.order / kp.order_cells (buffers d_cost, d_order,
+// d_counters of at least `cells` entries / 512 counters) and turns the spread off.  Everything is
+// enqueued on `s` ahead of the render launch.
+int enqueue_pixel_order(KParams &kp, bool fast, const float *d_scene, unsigned char *d_cost, unsigned int *d_order,
+                        unsigned int *d_counters, hipStream_t s)
+{
+    const int cells_x = kp.cells_x, cells_y = kp.my_bands * (RT_BAND_ROWS / 2);
+    const int ncells = cells_x * cells_y;
+    KParams pk = kp;
+    pk.max_depth = kp.max_depth < pilot_depth() ? kp.max_depth : pilot_depth();
+    pk.spp = 1; pk.light_grid = 1; pk.inv_light = 1.0f;
+    pk.deep = 0; pk.spread_shift = 6; pk.spread_stride = 0; pk.coop_rays = 0; pk.three_workgroups_per_cu = 0;
+    pk.pooled_trace = 1;
+    pk.pilot_cost = d_cost;
+    HIP_TRY(hipMemsetAsync(d_cost, 0, (size_t)ncells, s));                  // cells the frame's edge cuts off stay at 0
+    HIP_TRY(hipMemsetAsync(d_counters, 0, 512 * sizeof(unsigned int), s));
+    int lrc = fast ? rt_fast::launch_pilot(pk, d_scene, s) : rt_strict::launch_pilot(pk, d_scene, s);
+    if (lrc) return fail(RT_E_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    const int blocks = (ncells + 255) / 256;
+    hipLaunchKernelGGL(order_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, d_cost, ncells, d_counters);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, d_counters, d_counters + 256);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, s, d_cost, ncells, cells_x, d_counters + 256, d_order);
+    HIP_TRY(hipGetLastError());
+    kp.order = d_order;
+    kp.order_cells = ncells;
+    {
+        // the render launch's persistent waves: four per workgroup, as many workgroups as launch_variant starts
+        int wgs = ((ncells + 15) / 16 + 3) / 4;
+        if (wgs > kp.resident_workgroups) wgs = kp.resident_workgroups;
+        kp.order_deal = 4 * (wgs < 1 ? 1 : wgs);
+#ifdef RT_DEV_SWITCHES
+        if (getenv("RT_ORDER_DEAL")) kp.order_deal = atoi(getenv("RT_ORDER_DEAL")) > 0 ? atoi(getenv("RT_ORDER_DEAL")) : 1;
+#endif
+    }
+    kp.spread_shift = 6; kp.spread_stride = 0;
+    return RT_OK;
+}
+
+// Which deep frames get the pilot and the cost order: those with many pixels per lane of the GPU, whose
+// time is the work divided by the lanes that are kept busy (256 spheres 4K depth 16, 32 pixels per lane:
+// 281 -> 260 ms).  With few pixels per lane the frame lasts as long as the ray tree of its deepest pixel
+// takes one lane, and there the spread does as well or better (1080p, 8 pixels per lane: 256 spheres
+// 119 -> 124 ms, 1024 objects depth 16 44 -> 49 ms), so those keep it.
+bool wants_pixel_order(const KParams &kp, unsigned int flags)
+{
+    long long per_lane_x16 = 16ll * kp.resident_workgroups * 256;
+    if (flags & RT_FLAG_PIXEL_ORDER) per_lane_x16 = 1;
+#ifdef RT_DEV_SWITCHES
+    if (getenv("RT_NO_PILOT")) return false;
+    if (getenv("RT_PILOT_ALWAYS")) per_lane_x16 = 4096;
+#endif
+    return kp.deep && kp.use_hierarchy && (long long)kp.w * kp.my_bands * RT_BAND_ROWS >= per_lane_x16;
+}
+
 }  // namespace
 
 extern "C" {
@@ -513,6 +621,9 @@ static void release_all()
     if (g.d_events) (void)hipFree(g.d_events);
     if (g.d_work) (void)hipFree(g.d_work);
     if (g.d_pend_ws) (void)hipFree(g.d_pend_ws);
+    if (g.d_pilot_cost) (void)hipFree(g.d_pilot_cost);
+    if (g.d_order) (void)hipFree(g.d_order);
+    if (g.d_order_counters) (void)hipFree(g.d_order_counters);
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
     if (g.ws_event) (void)hipEventDestroy(g.ws_event);
@@ -532,6 +643,19 @@ static int ensure_workspace()
     static_assert(RT_PEND_MAX == RT_MAX_PENDING, "workspace slots per lane");
     size_t ws = (size_t)g.resident_workgroups * RT_PEND_MAX * 11 * 256 * sizeof(float);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pend_ws), ws));
+    return 0;
+}
+
+static int ensure_order_buffers(size_t cells)
+{
+    if (cells <= g.order_cap && g.d_order) return 0;
+    if (g.d_pilot_cost) HIP_TRY(hipFree(g.d_pilot_cost));
+    if (g.d_order) HIP_TRY(hipFree(g.d_order));
+    g.d_pilot_cost = nullptr; g.d_order = nullptr; g.order_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_pilot_cost), cells));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_order), cells * sizeof(unsigned int)));
+    if (!g.d_order_counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_order_counters), 512 * sizeof(unsigned int)));
+    g.order_cap = cells;
     return 0;
 }
 
@@ -774,9 +898,19 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
         if (wrc) return wrc;
         kp.pend_ws = g.d_pend_ws;
     }
+    const bool pixel_order = wants_pixel_order(kp, p->flags);
+    if (pixel_order) {
+        // (the order's buffers grow with the first deep frame of a size; they are shared like the workspace)
+        int orc = ensure_order_buffers((size_t)kp.cells_x * kp.my_bands * (RT_BAND_ROWS / 2));
+        if (orc) return orc;
+    }
     // (a wait on an event recorded on the same stream costs nothing on the GPU)
     if (shares_workspace && g.ws_busy) HIP_TRY(hipStreamWaitEvent(s, g.ws_event, 0));
     if (timed) HIP_TRY(hipEventRecord(g.ev0, s));
+    if (pixel_order) {
+        int orc = enqueue_pixel_order(kp, (p->flags & RT_FLAG_FAST_MATH) != 0, g.d_scene, g.d_pilot_cost, g.d_order, g.d_order_counters, s);
+        if (orc) return orc;
+    }
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, g.d_scene, d_out, s, &info)
                                              : rt_strict::launch_render(kp, g.d_scene, d_out, s, &info);
     if (lrc) return fail(RT_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));

@@ -105,6 +105,9 @@ enum { ST_PATH = 0, ST_SHADOW = 1 };
 // DEEP (persistent hierarchy kernels): the code for frames of deep path trees -- a wave's pixels
 // come from 64 different tiles (kp.spread_shift / kp.spread_stride), and a wave with at most
 // kp.coop_rays rays left traces them one at a time with all lanes (trace_cooperative).
+// PILOT (persistent hierarchy kernels): the launch that ranks the pixels of a deep frame by cost.  A lane's
+// "pixel" is the top-left pixel of a 2x2 pixel cell; instead of a colour the lane stores the number of rays
+// the pixel's tree took (to the small depth the host sets), saturated to a byte (kp.pilot_cost).
 // PEND: where the pending-ray slots live: PEND_REG registers (CAP of them, compare/select
 // addressing), PEND_LDS ([slot][field][thread] after the scene), PEND_GLOBAL (same layout in a
 // per-workgroup slice of a global workspace; persistent-wave kernels only, whose grid is
@@ -126,7 +129,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_WG_ONE 64
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false>
 __global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? (MULTI ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU_HIER1) : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
@@ -322,9 +325,14 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 #endif
     const bool in_frame = active;       // fixed pixel per lane (without REFILL)
     // wave-uniform queue state (REFILL): the tile being handed out and its next unassigned pixel
-    const int tiles_x8 = (kp.w + 7) >> 3;
-    const int tile_rows8 = kp.my_bands * 2;
-    const int ntiles = tiles_x8 * tile_rows8;
+    // (the pilot launch walks the grid of 2x2 pixel cells: half as many columns and rows)
+    const int tiles_x8 = PILOT ? (kp.cells_x + 7) >> 3 : (kp.w + 7) >> 3;
+    const int tile_rows8 = PILOT ? kp.my_bands : kp.my_bands * 2;
+    const bool ordered = DEEP && !PILOT && kp.order != nullptr;     // pixels handed out in the pilot's order
+    // (whole blocks of kp.order_deal entries: the last block's entries reach past the end of the order and stop there)
+    const int ntiles = ordered ? ((kp.order_cells + 16 * kp.order_deal - 1) / (16 * kp.order_deal)) * kp.order_deal : tiles_x8 * tile_rows8;
+    int nrays_pixel = 0;                                            // PILOT: rays of the current pixel so far
+    (void)nrays_pixel;
     int pool_tile = -1, pool_next = 64;
     int sq = (int)((blockIdx.x * 4u + (unsigned int)wave) % RT_SUBQUEUES), sq_tried = 0;
     bool exhausted = false;
@@ -374,7 +382,27 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                     int idx = pool_next + my;
                     int tile = idx < 64 ? pool_tile : new_tile;
                     idx &= 63;
-                    if (tile >= 0) {
+                    if (DEEP && ordered) {
+                        // Queue entry `tile` = 16 cells of the cost order, four lanes (2x2 pixels) per cell.  The
+                        // order is dealt out like cards: the entries come in blocks of kp.order_deal (one entry
+                        // per persistent wave), and inside a block entry e takes the cells e, e + deal,
+                        // e + 2 deal, ... of the block's stretch of the order -- every wave starts with the same
+                        // mix of the most expensive pixels instead of the first wave with the 64 deepest ones.
+                        const int blk = tile / kp.order_deal, eo = tile - blk * kp.order_deal;
+                        const int ci = (blk * 16 + (idx >> 2)) * kp.order_deal + eo;
+                        if (tile >= 0 && ci < kp.order_cells) {
+                            const unsigned int cell = kp.order[ci];
+                            px = (int)(cell & 0xffffu) * 2 + (idx & 1);
+                            packed_row = (int)(cell >> 16) * 2 + ((idx >> 1) & 1);
+                            const int row = (kp.part + (packed_row >> 4) * kp.nparts) * 16 + (packed_row & 15);
+                            if (px < kp.w && row < kp.h) {
+                                gy = kp.bottom_up ? row : (kp.h - 1 - row);
+                                if (MULTI) { accr = accg = accb = 0.0f; sample = 0; si = 0; sj = 0; }
+                                start_sample();
+                                active = true;
+                            }
+                        }
+                    } else if (tile >= 0) {
                         // Spread: queue entry `tile` stands for pixel groups (1 << spread_shift lanes each) of
                         // 64 >> spread_shift different tiles, kp.spread_stride apart in the tile sequence,
                         // so that a cluster of deep pixels ends up a few lanes each in many waves.  Slot idx
@@ -391,6 +419,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                         const int tx = (col & 1) ? (mid8 - 1 - (col >> 1)) : (mid8 + (col >> 1));
                         px = tx * 8 + (idx & 7);
                         packed_row = ty * 8 + (idx >> 3);
+                        if (PILOT) { px *= 2; packed_row *= 2; nrays_pixel = 0; }       // the cell's top-left pixel
                         const int row = (kp.part + (packed_row >> 4) * kp.nparts) * 16 + (packed_row & 15);
                         if (px < kp.w && row < kp.h) {
                             gy = kp.bottom_up ? row : (kp.h - 1 - row);
@@ -439,6 +468,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         do {
         if (REFILL && !active) break;
         if (SYNC && (!active || parked)) break;
+        if (PILOT) nrays_pixel++;
         // [census: trace_call @ ITER]
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
@@ -779,7 +809,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 } else {
                     active = false;
                 }
-                if (REFILL && !active) write_pixel();
+                if (PILOT) {
+                    if (!active) kp.pilot_cost[(size_t)(packed_row >> 1) * kp.cells_x + (px >> 1)] = (unsigned char)(nrays_pixel < 255 ? nrays_pixel : 255);
+                } else if (REFILL && !active) write_pixel();
 #ifdef RT_DEV_SWITCHES
                 if (REFILL && !active) dev_pixels++;
 #endif
@@ -823,7 +855,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 __global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
@@ -836,7 +868,8 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     static_assert(!DEEP || (HIER && REFILL && !DEBUG), "the deep-frame code belongs to the persistent hierarchy kernels");
     static_assert(POOL || !DEEP, "deep frames always pool");
     static_assert(!TOPPOOL || (POOL && HIER && REFILL && !DEBUG), "the pooled top-node loop is part of the pooled trace");
-    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL, TOPPOOL>;
+    static_assert(!PILOT || (HIER && REFILL && POOL && !DEEP && !MULTI && !DEBUG), "the pilot is a shallow single-sample launch of the pooled hierarchy kernel");
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL, TOPPOOL, PILOT>;
     size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
@@ -863,7 +896,7 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     if (REFILL) {
         // persistent waves: no more workgroups than the queue has work for or the GPU can hold
         if (!kp.work_counter) return (int)hipErrorInvalidValue;
-        const int ntiles = ((kp.w + 7) / 8) * my_bands * 2;
+        const int ntiles = PILOT ? ((kp.cells_x + 7) / 8) * my_bands : ((kp.w + 7) / 8) * my_bands * 2;
         int wgs = (ntiles + 3) / 4;
         if (wgs > kp.resident_workgroups) wgs = kp.resident_workgroups;
         grid = dim3(wgs < 1 ? 1 : wgs, 1);
@@ -898,7 +931,7 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     const bool no_ldsp = dev_no_ldsp;
     const bool multi = kp.spp > 1 || kp.light_grid > 1;      // sample loops: pixel samples, light samples
     // deep frames (the host's choice, see make_kparams): pixels spread over waves + cooperative trace
-    const bool deep = kp.coop_rays > 0 || kp.spread_shift < 6;
+    const bool deep = kp.deep != 0;
     const bool pool = kp.pooled_trace != 0;         // (the host's choice as well)
     const bool toppool = (pool || deep) && kp.pooled_top != 0;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
@@ -948,6 +981,16 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
 #undef RT_LAUNCH_HIER
 #undef RT_LAUNCH_HIER_M
 #undef RT_LAUNCH_HIER_V
+}
+
+// The pilot launch of a deep frame (see KParams::pilot_cost): kp carries the small depth and the cost buffer.
+int launch_pilot(const KParams &kp, const float *d_scene, void *stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!kp.pilot_cost || kp.cells_x <= 0) return (int)hipErrorInvalidValue;
+    if (kp.pooled_top)
+        return launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, true, true, false, true, true, true>(kp, d_scene, nullptr, nullptr, nullptr, s, nullptr);
+    return launch_variant<RT_PEND_MAX, false, PEND_GLOBAL, false, true, true, false, true, false, true>(kp, d_scene, nullptr, nullptr, nullptr, s, nullptr);
 }
 
 int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events, float *d_capture,

@@ -108,6 +108,19 @@ struct KParams {
     int pooled_trace;       // hierarchy kernels: pool the wave's member tests and intersections (trace_hierarchy_flat)
     int coop_rays;          // persistent hierarchy kernels: a wave with at most this many rays left traces them
                             // one at a time with all lanes (0: never)
+    int deep;               // deep frame: run the instantiation that carries the spread / cooperative trace / pixel order
+    // Deep frames, cost-ordered pixels.  A pilot launch of the same kernel (PILOT instantiation) traces
+    // the top-left pixel of every 2x2 pixel cell of this part to a small depth and stores the number of
+    // rays it took (pilot_cost, one byte per cell, cells in packed-row order, cells_x per row); two
+    // small kernels turn that into `order`: the cells sorted by that number, largest first, each as
+    // (cell row << 16) | cell column.  The render launch then hands out pixels in that order -- queue
+    // entry e = the 16 cells order[16 e ..] -- so the pixels with the deepest ray trees start first and
+    // the frame does not end with a few lanes walking through them while the rest of the GPU idles.
+    unsigned char *pilot_cost;      // pilot launch: where the ray counts go
+    const unsigned int *order;      // render launch: the sorted cells (null: tile order)
+    int order_cells;                // cells in `order`
+    int order_deal;                 // queue entries per block of the dealt order (the persistent waves of the launch)
+    int cells_x;                    // cells per row of this part: ceil(w / 2)
 #ifdef RT_DEV_SWITCHES
     int dev_stats;                  // development builds: collect the cut-off statistics of the pooled trace (slow)
     unsigned long long *wave_log;   // development builds: per persistent wave {start, end (100 MHz ticks), loop trips, pixels,
@@ -179,6 +192,7 @@ inline bool rt_uses_workspace(const KParams &kp) { return rt_variant_family(kp) 
     namespace NS {                                                                               \
     int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *stream,       \
                       LaunchInfo *info);                                                         \
+    int launch_pilot(const KParams &kp, const float *d_scene, void *stream);                    \
     int launch_debug(const KParams &kp, const float *d_scene, unsigned long long *d_events,     \
                      float *d_capture, void *stream);                                            \
     void set_dev_switch(int which, int value);                                                   \

@@ -128,6 +128,38 @@ def test_deep_frames_spread_and_cooperative_trace_equal_oracle(gpu_rt, orc, case
     assert f32_identical(f32, ref)
 
 
+@pytest.mark.parametrize("case", ["mixed200", "mixed1024", "spheres256", "tori64"])
+@pytest.mark.parametrize("size", [(203, 117), (64, 40), (9, 3)])
+def test_deep_frames_in_cost_order_equal_oracle(gpu_rt, orc, case, size):
+    """Deep frames with the pixels handed out in the order of a pilot launch (largest ray trees first,
+    dealt over the waves; what large deep frames do by themselves, forced here at small sizes):
+    ragged sizes, a frame smaller than one queue entry, tori, several samples per pixel, and a
+    band-split part."""
+    scene, cam = {"mixed200": (lambda: gpu_rt.mixed_scene(200), gpu_rt.mixed_camera),
+                  "mixed1024": (lambda: gpu_rt.mixed_scene(1024), gpu_rt.mixed_camera),
+                  "spheres256": (gpu_rt.spheres_deep_scene, gpu_rt.spheres_deep_camera),
+                  "tori64": (gpu_rt.tori_stress_scene, gpu_rt.tori_stress_camera)}[case]
+    scene, cam = scene(), cam()
+    w, h = size
+    o = dict(max_depth=12, stack_size=9, shadow_hops=3)
+    if case == "mixed200":
+        o["spp_grid"] = 2
+    f32 = gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, pixel_order=True, **o)
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, **o)["f32"]
+    assert f32_identical(f32, ref)
+    if size == (203, 117):
+        from importlib import import_module
+        tiling = import_module("ray-tracing_amd.tiling")
+        full = gpu_rt.render_rgba(scene, cam, w, h, pixel_order=True, **o)
+        for nparts in (3,):
+            rows = tiling.padded_part_rows(h, nparts)
+            gathered = np.zeros((nparts, rows, w, 4), dtype=np.uint8)
+            for part in range(nparts):
+                p = gpu_rt.render_rgba(scene, cam, w, h, part=part, nparts=nparts, pixel_order=True, **o)
+                gathered[part, :p.shape[0]] = p
+            assert np.array_equal(tiling.assemble_numpy(gathered, h, nparts), full)
+
+
 def test_deep_frame_in_parts_equals_whole_frame(gpu_rt):
     """The spread of pixels over waves is per part (its own tile sequence): parts reassemble to the frame."""
     from importlib import import_module
