@@ -338,7 +338,9 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     bool exhausted = false;
     if (!REFILL && active) start_sample();
 
+    cnt.tick0();
     for (;;) {
+        cnt.tick(HS_T_SHADE);
         if (!REFILL) {
             if (SYNC) {
                 // lanes start sample k+1 together, once the whole wave has finished sample k
@@ -449,6 +451,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         constexpr bool FLAT = HIER && REFILL && !DEBUG && POOL && RT_FLAT;
         float t_coop = 0.0f; int id_coop = -1;
         bool coop = false;      // this trip's trace is done here, by the whole wave (wave-uniform)
+        cnt.tick(HS_T_HEAD);
         if (COOP) {
             const int nrays = __popcll(__ballot(active));
             if (nrays <= kp.coop_rays) {
@@ -456,6 +459,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 coop = true;
             }
         }
+        cnt.tick(HS_T_COOP);
         if (FLAT && !coop) {
             trace_hierarchy_flat<DEBUG, TOPPOOL>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
             coop = true;
@@ -764,7 +768,6 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
                 }
             }
         }
-
         if (pop) {
             // [census: pop @ POP]
             WCNT(WP_POP);
@@ -830,11 +833,15 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
         if constexpr (!DEBUG) {
             unsigned long long *w = kp.wave_log + ((size_t)blockIdx.x * 4 + wave) * RT_WAVE_LOG_WORDS;
-            for (int k = 0; k < HS_COUNT; ++k) {
+#ifndef RT_DEV_TIMERS_ONLY
+            for (int k = 0; k < HS_T_HEAD; ++k) {
                 unsigned long long a = cnt.hs_wave[k], b = cnt.hs_lane[k];
                 for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
                 if (lane == 0) { w[4 + k] = a; w[4 + HS_COUNT + k] = b; }
             }
+#endif
+            for (int k = HS_T_HEAD; k < HS_COUNT; ++k)
+                if (lane == 0) w[4 + k] = cnt.hs_time[k - HS_T_HEAD];
         }
     }
 #endif

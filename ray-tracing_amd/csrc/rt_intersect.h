@@ -16,6 +16,9 @@ enum { HS_TOP, HS_LEAF, HS_CAND, HS_SCAN, HS_COOP_RAY, HS_COOP_ROUND,
        // development statistics of the pooled trace (lane sums only)
        HS_RAYS, HS_RAYS_SHADOW, HS_RAYS_HIT, HS_KEPT, HS_KEPT_NEEDED, HS_KEPT_SHADOW_NEEDED, HS_CANDS, HS_CANDS_NEEDED,
        HS_TORUS_ROUND, HS_RAYS_NEAR_HIT,
+       // development timers (core clock cycles per wave, as wave-level sums): loop head + refill, cooperative trace,
+       // node tests + item lists, leaf rounds, exact rounds, owner + replay, shading
+       HS_T_HEAD, HS_T_COOP, HS_T_SCAN, HS_T_LEAF, HS_T_EXACT, HS_T_OWNER, HS_T_SHADE,
        HS_COUNT };
 template <bool DEBUG> struct Counters {
     unsigned int *lds_ev;
@@ -24,6 +27,7 @@ template <bool DEBUG> struct Counters {
     DEV void lanes(int) const {}
     DEV bool counting_events() const { return false; }
 #ifdef RT_DEV_SWITCHES
+#ifndef RT_DEV_TIMERS_ONLY
     // development builds: loop iterations of the hierarchy walk, per wave (the lowest active lane counts) and per lane
     mutable unsigned int hs_wave[HS_COUNT] = {}, hs_lane[HS_COUNT] = {};
     DEV void hstat(int k) const
@@ -33,6 +37,20 @@ template <bool DEBUG> struct Counters {
     }
     DEV void hadd(int k, unsigned int n) const { hs_lane[k] += n; }
 #else
+    // (-DRT_DEV_TIMERS_ONLY: the phase timers alone; the per-lane counters cost the kernels so many registers that
+    // the shares of the phases no longer are those of the product build)
+    DEV void hstat(int) const {}
+    DEV void hadd(int, unsigned int) const {}
+#endif
+    // Phase timers: tick(k) charges the cycles since the last tick to phase k (wave-uniform values).  Coarse
+    // phases only: every tick is a scalar memory instruction the wave waits for, and the compiler may move
+    // arithmetic across it, so shares of short stretches of code are not to be trusted.
+    mutable unsigned long long t_last = 0, hs_time[HS_COUNT - HS_T_HEAD] = {};
+    DEV void tick0() const { t_last = __builtin_amdgcn_s_memtime(); }
+    DEV void tick(int k) const { const unsigned long long t = __builtin_amdgcn_s_memtime(); hs_time[k - HS_T_HEAD] += t - t_last; t_last = t; }
+#else
+    DEV void tick0() const {}
+    DEV void tick(int) const {}
     DEV void hstat(int) const {}
 #endif
 };
@@ -51,6 +69,8 @@ template <> struct Counters<true> {
     // the event counts are the reference's work, object by object: no shortcuts while counting
     DEV bool counting_events() const { return !wave_mode; }
     DEV void hstat(int) const {}
+    DEV void tick0() const {}
+    DEV void tick(int) const {}
 };
 #define CNT(ev) cnt.add(ev)
 #define WCNT(slot) cnt.wave(slot)
@@ -852,6 +872,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     // all lanes on tori instead of in every round with the few lanes that happen to hold one.  An
     // item moved to the second stack has just left the first, so both always fit: fewer than 64 of
     // each wait when a leaf round starts, which appends at most 64 x RT_LEAF.
+    cnt.tick(HS_T_SCAN);
     int ncand = 0, ntor = 0;          // wave-uniform: items on the mixed stack / on the tori stack
     auto offer_hit = [&](int r, int i, float t, bool hit) {
         if (hit && t < 1e30f) {
@@ -880,6 +901,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
     };
     // full rounds while 64 items wait; with `all` also the partial last ones
     auto exact_rounds = [&](bool all) {
+        cnt.tick(HS_T_LEAF);
         while (ncand >= 64 || (all && ncand > 0)) {
             // [census: flat_exact_round @ FLAT_EXACT]
             HSTAT(HS_CAND);
@@ -903,6 +925,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             if (lane < take) exact_item(clist[RT_FLAT_CAND - ntor + lane], true);
             ntor -= take;
         }
+        cnt.tick(HS_T_EXACT);
     };
 
     const unsigned int *slot_pair = reinterpret_cast<const unsigned int *>(slot_id);     // the ids of slots 2k, 2k + 1
@@ -921,6 +944,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             else { leaf = 64 + __builtin_ctzll(leaf_hi); leaf_hi &= leaf_hi - 1; }
             items[at++] = (unsigned short)((lane << 8) | leaf);
         }
+        cnt.tick(HS_T_SCAN);
         for (int base = 0; base < total; base += 64) {
             // [census: flat_leaf_round @ FLAT_LEAF]
             HSTAT(HS_LEAF);
@@ -979,6 +1003,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             if (ncand + ntor > RT_FLAT_CAND - 64 * RT_LEAF) exact_rounds(false);
         }
     }
+    cnt.tick(HS_T_LEAF);
     exact_rounds(true);
 
     // [census: flat_owner @ ITER]
@@ -1027,6 +1052,7 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
         offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
         best_t = bt; best_id = bid;
     }
+    cnt.tick(HS_T_OWNER);
 }
 
 #ifdef RT_DEV_SWITCHES

@@ -140,7 +140,7 @@ enum RtEvent {
     EV_REFR_TRY, EV_REFR_PUSH, EV_REFL_EVAL, EV_REFL_PUSH, EV_DROP,
     EV_COUNT
 };
-#define RT_WAVE_LOG_WORDS 48
+#define RT_WAVE_LOG_WORDS 64
 #define RT_COUNTER_SLOTS 64      // counters the instrumented kernel keeps (events, or the wave profile's blocks)
 static_assert(EV_COUNT <= RT_COUNTER_SLOTS, "event counters");
 

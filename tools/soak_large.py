@@ -2,7 +2,8 @@
 """Soak run: many seeded large random scenes (100-700 objects: nested, duplicated, outlying ones,
 cameras inside and far outside), accelerated kernels against the plain per-object loop; float32
 frames must be identical.  Every third seed runs as a deep frame (max_depth 12-16, 8-16 pending
-rays: pixels spread over waves, cooperative trace).
+rays: pixels spread over waves, cooperative trace; every other one of those with the pixels handed
+out in the cost order of a pilot launch).
 usage: tools/soak_large.py first_seed last_seed"""
 import os
 import sys
@@ -20,10 +21,11 @@ for seed in range(a, b):
         o = dict(o, max_depth=12 + seed % 5, stack_size=8 + seed % 9)
     w, h = 160 + 8 * (seed % 7), 90 + 5 * (seed % 5)
     spp = 2 if seed % 4 == 0 else 1
-    x = rt355.render_rgba(scene, cam, w, h, out_f32=True, spp_grid=spp, **o)
+    ordered = seed % 3 == 2 and seed % 2 == 0
+    x = rt355.render_rgba(scene, cam, w, h, out_f32=True, spp_grid=spp, pixel_order=ordered, **o)
     y = rt355.render_rgba(scene, cam, w, h, out_f32=True, spp_grid=spp, no_accel=True, **o)
     same = np.array_equal(np.where(np.isnan(x), np.float32(7), x), np.where(np.isnan(y), np.float32(7), y))
     bad += not same
-    print(seed, len(scene), o, w, h, spp, "ok" if same else "MISMATCH", flush=True)
+    print(seed, len(scene), o, w, h, spp, "cost order" if ordered else "", "ok" if same else "MISMATCH", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -42,7 +42,7 @@ def main():
         lib.rt_dev_wave_log_clear()
         assert lib.rt_render_device(ctypes.addressof(p), buf.data_ptr(), buf.numel(), None, 1) == 0, lib.rt_last_error()
         lib.rt_get_timing(ctypes.addressof(t))
-    WORDS = 48      # RT_WAVE_LOG_WORDS
+    WORDS = 64      # RT_WAVE_LOG_WORDS
     log = np.zeros((8192, WORDS), dtype=np.uint64)
     n = lib.rt_dev_wave_log(log.ctypes.data, 8192)
     log = log[:n]
@@ -62,13 +62,19 @@ def main():
     us_per_trip = (log[:, 1] - log[:, 0]) / 100.0 / np.maximum(trips, 1)
     print(f"microseconds per loop trip: p10 {np.percentile(us_per_trip, 10):.2f}  p50 {np.percentile(us_per_trip, 50):.2f}  p90 {np.percentile(us_per_trip, 90):.2f}")
     names = ["top-node loop", "leaf loop", "candidate loop (step 2)", "queue scan reads", "cooperative rays", "cooperative rounds"]
-    HS = 16         # HS_COUNT (rt_intersect.h)
+    HS = 23         # HS_COUNT (rt_intersect.h)
     tot_trips = trips.sum()
     print("hierarchy walk, loop iterations per loop trip of a wave (wave-level = instructions issued; lanes = mean lanes in it):")
     for k, nm in enumerate(names):
         wv, ln = log[:, 4 + k].sum(), log[:, 4 + HS + k].sum()
         print(f"  {nm:26s} {wv / max(tot_trips, 1):8.2f} per trip   lanes per iteration {ln / max(wv, 1):6.1f}")
     print(f"  {'torus rounds':26s} {log[:, 4 + 14].sum() / max(tot_trips, 1):8.2f} per trip")
+    tnames = ["loop head + refill", "cooperative trace", "node tests + item lists", "leaf rounds", "exact rounds", "owner + replay", "shading + state machine"]
+    tt = [log[:, 4 + 16 + k].sum() for k in range(7)]
+    if sum(tt) > 0:
+        print("cycles of a wave by phase (s_memtime deltas; other waves of the SIMD run in between):")
+        for nm, v in zip(tnames, tt):
+            print(f"  {nm:34s} {100 * v / sum(tt):6.1f} %   {v / max(tot_trips, 1):9.0f} cycles per trip")
     stats = ["rays", "shadow rays", "rays that hit an object", "kept leaf nodes", "kept leaf nodes in front of the hit",
              "the same, shadow rays also cut at the light", "candidates", "candidates in front of the hit", "-", "rays with a hit closer than 1"]
     tot = [log[:, 4 + HS + 6 + k].sum() for k in range(len(stats))]
