@@ -106,6 +106,107 @@ def executed_work(workload, fast_math, kernel_ms):
         return None
 
 
+def main_inlib(args, wl):
+    """--multi inlib: ONE process drives all N GPUs through rt_init_multi (each device renders its
+    bands and copies them straight into the frame on device 0; no RCCL).  Launched directly, or under
+    torch.distributed.run, where rank 0 does the work and the other ranks leave at once.  On a machine
+    with fewer than N GPUs the parts share the devices there are (a rehearsal of the code path; the
+    line says so)."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    import hashlib
+    import torch
+    import rt355
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(n)]
+    lib = rt355.init_multi(devices=devices)
+    scene, cam = {"default": (rt355.default_scene, rt355.default_camera),
+                  "tori": (rt355.tori_stress_scene, rt355.tori_stress_camera),
+                  "spheres": (rt355.spheres_deep_scene, rt355.spheres_deep_camera),
+                  "mixed": (rt355.mixed_scene, rt355.mixed_camera)}[wl["scene"]]
+    scene, cam = scene(), cam()
+    rt355.set_scene(scene)
+    flags = rt355.api.FLAG_FAST_MATH if args.fast_math else 0
+    params = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size, shadow_hops=SHADOW_HOPS,
+                                   spp_grid=wl["spp_grid"], flags=flags)
+    pptr = ctypes.addressof(params)
+    dev0 = torch.device("cuda", devices[0])
+    torch.cuda.set_device(dev0)
+    nbuf = 4
+    streams = [torch.cuda.Stream(device=dev0) for _ in range(nbuf)]
+    frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev0) for _ in range(nbuf)]
+    sptrs = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams]
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(lib.rt_last_error().decode())
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def run(steps, rotate):
+        for i in range(steps):
+            k = i % nbuf if rotate else 0
+            check(lib.rt_render_device(pptr, frames[k].data_ptr(), frames[k].numel(), sptrs[k], 0))
+
+    run(args.warmup, False)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps, False)
+    host_issue_s = time.perf_counter() - t0
+    sync_all()
+    ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
+    # informational: consecutive frames on rotating streams / frame buffers (the last waves of a frame overlap the next one)
+    run(nbuf, True)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    sync_all()
+    ms_rotating = (time.perf_counter() - t0) * 1e3 / args.steps
+    # one timed frame: kernel alone and copy alone, per part
+    check(lib.rt_render_device(pptr, frames[0].data_ptr(), frames[0].numel(), sptrs[0], 1))
+    sync_all()
+    parts = []
+    for i in range(n):
+        try:
+            k, c = rt355.api.part_timing(i)
+            parts.append({"part": i, "device": devices[i], "kernel_ms": k, "copy_ms": c})
+        except rt355.RtError:
+            parts.append({"part": i, "device": devices[i], "kernel_ms": None, "copy_ms": None})
+    headline = args.workload == "default4k"
+    mpix = W * H * wl["spp_grid"] ** 2 / 1e6
+    result = {
+        "metric": "Mpixel-paths/s at 3840x2160 (default scene, max bounce depth 8)" if headline else "Mpixel-paths/s (%s)" % args.workload,
+        "value": mpix / (ms_per_step * 1e-3), "unit": "Mpixel-paths/s", "fps": 1e3 / ms_per_step, "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (the reference's default scene and camera; no dataset exists)" if headline
+                                else "synthetic (seeded stress scene of the benchmark list)",
+        "config": {"workload": wl["text"] % wl, "numerics": "fast" if args.fast_math else "strict (bit-identical to the reference shader)",
+                   "tiling": "in-library: one process, %d parts of interleaved 16-row bands on devices %s, strided peer copies into the frame on device %d"
+                             % (n, devices, devices[0])},
+        "host_issue_ms_per_step": host_issue_s * 1e3 / args.steps,
+        "rotating_streams": {"streams": nbuf, "ms_per_step": ms_rotating, "note": "not the reported value"},
+        "parts": parts,
+        "kernel_only_ms_per_step": max((p_["kernel_ms"] or 0.0) for p_ in parts),
+        "kernel_plus_copy_ms_per_step": max(((p_["kernel_ms"] or 0.0) + (p_["copy_ms"] or 0.0)) for p_ in parts),
+    }
+    if len(set(devices)) < n:
+        result["rehearsal"] = "%d parts on %d GPU(s): the code path, not a scaling measurement" % (n, len(set(devices)))
+    golden_name = {"default4k": "default_4k_d8s3", "tori64_4k": "tori64_4k_d8s3"}.get(args.workload)
+    golden_file = os.path.join(ROOT, "tests", "golden", "%s.json" % golden_name) if golden_name else None
+    if golden_file and os.path.exists(golden_file) and not args.fast_math and args.stack_size == WORKLOADS[args.workload]["stack_size"]:
+        golden = json.load(open(golden_file))
+        got = hashlib.sha256(frames[0].flip(0).contiguous().cpu().numpy().tobytes()).hexdigest()
+        result["frame_sha_ok"] = got == golden["sha256_rgba8"]
+    else:
+        result["frame_sha_ok"] = None
+    result["library"] = rt355.api.library_fingerprint()
+    print(json.dumps(result))
+    rt355.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +218,8 @@ def main():
     ap.add_argument("--roofline", action="store_true",
                     help="also for the other workloads: count the frame's events with the instrumented kernel (slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", default="rccl", choices=["rccl", "inlib"],
+                    help="N > 1: one process per GPU with an RCCL gather (default), or one process driving all GPUs inside the library")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     wl_default_stack = wl["stack_size"]
@@ -126,6 +229,8 @@ def main():
     headline = args.workload == "default4k"
     global W, H, MAX_DEPTH, SHADOW_HOPS
     W, H, MAX_DEPTH, SHADOW_HOPS = wl["w"], wl["h"], wl["max_depth"], wl["shadow_hops"]
+    if args.multi == "inlib":
+        return main_inlib(args, wl)
 
     # Multi-GPU runs keep several frames in flight on separate streams; HIP gives a process four
     # hardware queues by default and streams that share a queue do not overlap, so ask for eight
@@ -227,6 +332,18 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # The frame's work (event counters of the instrumented kernel, for the roofline) is counted before the
+    # timed steps, not after them: it is set-up like the scene upload, and a GPU that has just run a
+    # kernel of several milliseconds has left its idle clocks (measured: the first ~30 launches after an
+    # idle period take 0.30-0.32 ms each, later ones 0.28).
+    frame_events = None
+    if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
+        import numpy as np
+        full = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
+                                     shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags)
+        frame_events = np.zeros(lib.rt_event_count(), dtype=np.uint64)
+        check(lib.rt_count_events(ctypes.addressof(full), frame_events.ctypes.data))
 
     run(args.warmup)
     barrier()
@@ -333,13 +450,8 @@ def main():
                                            "note": "not the reported value: consecutive frames on rotating streams, host clock"}
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
-    if world == 1 and rank == 0 and not force_gather and (headline or args.roofline):
-        full = rt355.api.make_params(cam, W, H, max_depth=MAX_DEPTH, stack_size=args.stack_size,
-                                     shadow_hops=SHADOW_HOPS, spp_grid=wl["spp_grid"], flags=flags)
-        import numpy as np
-        ev = np.zeros(lib.rt_event_count(), dtype=np.uint64)
-        check(lib.rt_count_events(ctypes.addressof(full), ev.ctypes.data))
-        flops = rt355.frame_flops(ev)
+    if frame_events is not None:
+        flops = rt355.frame_flops(frame_events)
         kernel_ms = stream_ms / args.steps          # back-to-back launches of the one kernel on this stream
         tim = rt355.api.RtTiming()
         image = pipe.image

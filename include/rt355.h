@@ -126,11 +126,15 @@ int rt_init(int device);
  * rt_render reads it back / rt_render_device leaves it in the caller's buffer, the caller's
  * stream waiting for all parts.  rt_init_multi_devices takes the device of every part explicitly;
  * a device may appear more than once (its parts then share that GPU), which is also how the
- * multi-part path is exercised on a machine with one GPU.  Kernel timing (timed != 0), the event
- * counters and rt_render_device_noalloc stay single-device features of device 0.            */
+ * multi-part path is exercised on a machine with one GPU.  The event counters and
+ * rt_render_device_noalloc stay single-device features of device 0.  A timed frame (timed != 0)
+ * records, per part, events around its kernel and around its copy into the frame:
+ * rt_get_part_timing returns the two intervals of part `part` (kernel alone; strided copy to
+ * device 0 alone), and rt_get_timing's kernel_ms is then the slowest part's kernel.          */
 int rt_init_multi(int n_devices);
 int rt_init_multi_devices(const int *devices, int n);
 int rt_device_count(void);        /* parts a frame is split into: 0 before rt_init, 1 after rt_init */
+int rt_get_part_timing(int part, float *kernel_ms, float *copy_ms);
 
 /* Host-only helper (no GPU): the output row of every packed row of part `part` of `nparts`, in
  * buffer order; returns their number (rows may be NULL to ask for it).                       */

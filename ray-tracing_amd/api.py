@@ -67,7 +67,7 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_set_scene", "rt_output
            "rt_render", "rt_assemble_device", "rt_get_timing", "rt_count_events", "rt_event_count",
            "rt_event_flops", "rt_event_name", "rt_capture_segment", "rt_selftest_math", "rt_stage_scene_host",
            "rt_render_device_noalloc", "rt_host_alloc", "rt_host_free", "rt_init_multi", "rt_init_multi_devices", "rt_device_count",
-           "rt_part_row_map"]
+           "rt_part_row_map", "rt_get_part_timing"]
 
 
 def load_library():
@@ -91,6 +91,7 @@ def load_library():
     L.rt_init_multi.argtypes = [ci]
     L.rt_init_multi_devices.argtypes = [vp, ci]
     L.rt_part_row_map.argtypes = [ci, ci, ci, vp, ci]
+    L.rt_get_part_timing.argtypes = [ci, vp, vp]
     L.rt_host_alloc.argtypes = [sz]
     L.rt_host_alloc.restype = vp
     L.rt_host_free.argtypes = [vp]
@@ -150,6 +151,14 @@ def init_multi(n_devices=None, devices=None):
         _check(L.rt_init_multi_devices(arr, len(devices)))
     _inited_device = int(devices[0])
     return L
+
+
+def part_timing(part):
+    """(kernel_ms, copy_ms) of part `part` of the last timed frame in multi-device mode."""
+    L = _ensure_init()
+    k, c = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    _check(L.rt_get_part_timing(int(part), ctypes.byref(k), ctypes.byref(c)))
+    return float(k.value), float(c.value)
 
 
 def part_row_map(height, part, nparts):

@@ -68,6 +68,8 @@ struct State {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;          // this part's bands are in the frame
         hipEvent_t frame_free = nullptr;    // recorded on the frame's stream: the frame may be overwritten
+        hipEvent_t t_start = nullptr, t_kernel = nullptr, t_copy = nullptr;     // a timed frame: before the kernel, after it, after the copy
+        bool timed = false;                 // the three events of the last frame were recorded
         float *d_scene = nullptr; size_t d_scene_cap = 0;
         void *d_part = nullptr; size_t d_part_cap = 0;
         unsigned int *d_work = nullptr;
@@ -94,6 +96,7 @@ struct Issuers {
     bool stop = false;
     const rt_params *params = nullptr;      // the frame being issued
     void *d_frame = nullptr;
+    bool timed = false;                     // record the parts' timing events
     std::vector<int> rc;                    // per part: result of the last issue
     std::vector<std::string> err;           //           and its message
 } g_issuers;
@@ -607,6 +610,9 @@ static void release_parts()
         if (pt.d_pend_ws) (void)hipFree(pt.d_pend_ws);
         if (pt.done) (void)hipEventDestroy(pt.done);
         if (pt.frame_free) (void)hipEventDestroy(pt.frame_free);
+        if (pt.t_start) (void)hipEventDestroy(pt.t_start);
+        if (pt.t_kernel) (void)hipEventDestroy(pt.t_kernel);
+        if (pt.t_copy) (void)hipEventDestroy(pt.t_copy);
         if (pt.stream) (void)hipStreamDestroy(pt.stream);
     }
     g.parts.clear();
@@ -871,7 +877,7 @@ size_t rt_output_bytes(const rt_params *p)
     return (size_t)part_rows(p) * (size_t)p->width * bpp;
 }
 
-static int render_multi(const rt_params *p, void *d_frame, hipStream_t s);
+static int render_multi(const rt_params *p, void *d_frame, hipStream_t s, bool timed);
 
 int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *stream, int timed)
 {
@@ -883,10 +889,7 @@ int rt_render_device(const rt_params *p, void *d_out, size_t out_bytes, void *st
     if (!d_out && need) return fail(RT_E_ARG, "output pointer is null");
     if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : g.stream;
-    if (!g.parts.empty()) {
-        if (timed) return fail(RT_E_ARG, "kernel timing is per device: not available in multi-device mode");
-        return render_multi(p, d_out, s);
-    }
+    if (!g.parts.empty()) return render_multi(p, d_out, s, timed != 0);      // (timing per part: rt_get_part_timing)
     KParams kp = make_kparams(p);
     LaunchInfo info{};
     // the persistent-wave kernels of large scenes share one pending-ray workspace: a launch
@@ -984,7 +987,7 @@ int rt_part_row_map(int height, int part, int nparts, int32_t *rows, int capacit
 // assemble pass); `s` (a stream of the first device) continues once all parts are in.
 // Render part i of the frame on its device and copy its bands into the frame on the first device.
 // The caller has made the part's device current.
-static int issue_part(int i, const rt_params *p, void *d_frame)
+static int issue_part(int i, const rt_params *p, void *d_frame, bool timed)
 {
     const int np = (int)g.parts.size();
     const size_t bpp = (p->flags & RT_FLAG_OUT_F32) ? 16 : (p->flags & RT_FLAG_OUT_RGB8) ? 3 : 4;
@@ -1002,6 +1005,7 @@ static int issue_part(int i, const rt_params *p, void *d_frame)
         pt.d_part_cap = need ? need : 16;
     }
     const int my_bands = (bands - i + np - 1) / np;
+    pt.timed = false;
     if (my_bands <= 0) { HIP_TRY(hipEventRecord(pt.done, pt.stream)); return RT_OK; }
     KParams kp = make_kparams(&q);
     kp.work_counter = pt.d_work;
@@ -1012,10 +1016,12 @@ static int issue_part(int i, const rt_params *p, void *d_frame)
     }
     kp.pend_ws = pt.d_pend_ws;
     HIP_TRY(hipStreamWaitEvent(pt.stream, g.parts[0].frame_free, 0));
+    if (timed) HIP_TRY(hipEventRecord(pt.t_start, pt.stream));
     LaunchInfo info{};
     int lrc = (p->flags & RT_FLAG_FAST_MATH) ? rt_fast::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, i == 0 ? &info : nullptr)
                                              : rt_strict::launch_render(kp, pt.d_scene, pt.d_part, pt.stream, i == 0 ? &info : nullptr);
     if (lrc) return fail(RT_E_HIP, "kernel launch failed on device %d: %s", pt.device, hipGetErrorString((hipError_t)lrc));
+    if (timed) HIP_TRY(hipEventRecord(pt.t_kernel, pt.stream));
     // bands i, i + np, ...: contiguous in the part buffer, np bands apart in the frame
     const bool owns_tail = (bands - 1) % np == i && tail_rows != RT_BAND_ROWS;
     const int full = owns_tail ? my_bands - 1 : my_bands;
@@ -1025,6 +1031,7 @@ static int issue_part(int i, const rt_params *p, void *d_frame)
     if (owns_tail)
         HIP_TRY(hipMemcpyAsync(dst + (size_t)full * band_bytes * np, static_cast<char *>(pt.d_part) + (size_t)full * band_bytes,
                                row_bytes * tail_rows, hipMemcpyDeviceToDevice, pt.stream));
+    if (timed) { HIP_TRY(hipEventRecord(pt.t_copy, pt.stream)); pt.timed = true; }
     HIP_TRY(hipEventRecord(pt.done, pt.stream));
     if (i == 0) { g.timing.vgprs = info.vgprs; g.timing.lds_bytes = info.lds_bytes; g.timing.pending_cap = info.pending_cap; }
     return RT_OK;
@@ -1039,16 +1046,16 @@ static void issuer_main(int i)
     bool bound = hipSetDevice(g.parts[i].device) == hipSuccess;
     unsigned long long seen = 0;
     for (;;) {
-        const rt_params *p; void *d_frame;
+        const rt_params *p; void *d_frame; bool timed;
         {
             std::unique_lock<std::mutex> lk(is.m);
             is.wake.wait(lk, [&] { return is.stop || is.generation != seen; });
             if (is.stop) return;
             seen = is.generation;
-            p = is.params; d_frame = is.d_frame;
+            p = is.params; d_frame = is.d_frame; timed = is.timed;
         }
         err[0] = 0;
-        int rc = !p ? fail(RT_E_STATE, "no frame to issue") : bound ? issue_part(i, p, d_frame) : fail(RT_E_HIP, "the issuing thread of part %d could not select device %d", i, g.parts[i].device);
+        int rc = !p ? fail(RT_E_STATE, "no frame to issue") : bound ? issue_part(i, p, d_frame, timed) : fail(RT_E_HIP, "the issuing thread of part %d could not select device %d", i, g.parts[i].device);
         {
             std::lock_guard<std::mutex> lk(is.m);
             is.rc[i] = rc;
@@ -1058,7 +1065,7 @@ static void issuer_main(int i)
     }
 }
 
-static int render_multi(const rt_params *p, void *d_frame, hipStream_t s)
+static int render_multi(const rt_params *p, void *d_frame, hipStream_t s, bool timed)
 {
     const int np = (int)g.parts.size();
     if (p->nparts != 1 || p->part != 0) return fail(RT_E_ARG, "in multi-device mode the library splits the frame itself: part/nparts must be 0/1");
@@ -1067,13 +1074,13 @@ static int render_multi(const rt_params *p, void *d_frame, hipStream_t s)
     HIP_TRY(hipEventRecord(g.parts[0].frame_free, s));
     if (np > 1) {
         std::lock_guard<std::mutex> lk(is.m);
-        is.params = p; is.d_frame = d_frame;
+        is.params = p; is.d_frame = d_frame; is.timed = timed;
         is.pending = np - 1;
         is.generation++;
     }
     if (np > 1) is.wake.notify_all();
     // (no early return from here to the wait below: the issuing threads hold `p`)
-    int rc = hipSetDevice(g.parts[0].device) == hipSuccess ? issue_part(0, p, d_frame)
+    int rc = hipSetDevice(g.parts[0].device) == hipSuccess ? issue_part(0, p, d_frame, timed)
                                                             : fail(RT_E_HIP, "cannot select device %d", g.parts[0].device);
     if (np > 1) {
         std::unique_lock<std::mutex> lk(is.m);
@@ -1114,6 +1121,9 @@ int rt_init_multi_devices(const int *devices, int n)
             }
             HIP_TRY(hipStreamCreateWithFlags(&pt.stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&pt.done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreate(&pt.t_start));
+            HIP_TRY(hipEventCreate(&pt.t_kernel));
+            HIP_TRY(hipEventCreate(&pt.t_copy));
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pt.d_work), RT_SUBQUEUES * RT_SUBQUEUE_STRIDE * sizeof(unsigned int)));
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, pt.device));
@@ -1161,7 +1171,7 @@ int rt_render(const rt_object *objs, int n, const rt_params *p, void *out, size_
     if (out_bytes < need) return fail(RT_E_SIZE, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     rc = ensure_out(need);
     if (rc) return rc;
-    rc = rt_render_device(p, g.d_out, need, g.stream, g.parts.empty() ? 1 : 0);
+    rc = rt_render_device(p, g.d_out, need, g.stream, 1);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, g.d_out, need, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1189,6 +1199,20 @@ int rt_get_timing(rt_timing *t)
 {
     if (!t) return fail(RT_E_ARG, "timing pointer is null");
     if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (!g.parts.empty()) {
+        // multi-device mode: the slowest part's kernel of the last timed frame
+        float worst = 0.0f;
+        bool any = false;
+        for (int i = 0; i < (int)g.parts.size(); ++i) {
+            if (!g.parts[i].timed) continue;
+            float k = 0.0f, c = 0.0f;
+            int rc = rt_get_part_timing(i, &k, &c);
+            if (rc) return rc;
+            worst = k > worst ? k : worst;
+            any = true;
+        }
+        if (any) g.timing.kernel_ms = worst;
+    }
     if (g.ev_pending) {
         HIP_TRY(hipEventSynchronize(g.ev1));
         float ms = 0.0f;
@@ -1197,6 +1221,22 @@ int rt_get_timing(rt_timing *t)
         g.ev_pending = false;
     }
     *t = g.timing;
+    return RT_OK;
+}
+
+int rt_get_part_timing(int part, float *kernel_ms, float *copy_ms)
+{
+    if (!g.inited) return fail(RT_E_STATE, "rt_init has not been called");
+    if (g.parts.empty()) return fail(RT_E_STATE, "not in multi-device mode (rt_init_multi)");
+    if (part < 0 || part >= (int)g.parts.size() || !kernel_ms || !copy_ms) return fail(RT_E_ARG, "bad part timing arguments");
+    State::Part &pt = g.parts[part];
+    if (!pt.timed) return fail(RT_E_STATE, "the last frame was not timed (rt_render_device with timed != 0), or this part had no bands");
+    HIP_TRY(hipSetDevice(pt.device));
+    hipError_t e = hipEventSynchronize(pt.t_copy);
+    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms, pt.t_start, pt.t_kernel);
+    if (e == hipSuccess) e = hipEventElapsedTime(copy_ms, pt.t_kernel, pt.t_copy);
+    (void)hipSetDevice(g.device);
+    if (e != hipSuccess) return fail(RT_E_HIP, "part timing: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

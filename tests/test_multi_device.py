@@ -58,6 +58,15 @@ def test_multi_device_mode_equals_single_device_frames(gpu_rt):
                     assert lib.rt_render_device(ctypes.addressof(p), buf.data_ptr(), buf.numel(), ctypes.c_void_p(st.cuda_stream), 0) == 0
                 st.synchronize()
             assert np.array_equal(buf.cpu().numpy(), want[0][0])
+            # a timed frame reports every part's kernel and copy interval, and the frame is the same
+            assert lib.rt_render_device(ctypes.addressof(p), buf.data_ptr(), buf.numel(), ctypes.c_void_p(st.cuda_stream), 1) == 0, lib.rt_last_error()
+            st.synchronize()
+            assert np.array_equal(buf.cpu().numpy(), want[0][0])
+            times = [rt.api.part_timing(i) for i in range(len(devices))]
+            assert all(k > 0.0 and c >= 0.0 for k, c in times), times
+            assert abs(rt.timing()["kernel_ms"] - max(k for k, _ in times)) < 1e-6
+            with pytest.raises(rt.RtError):
+                rt.api.part_timing(len(devices))
             # the library splits the frame itself
             p2 = rt.api.make_params(cam, w, h, part=1, nparts=2, **o)
             assert lib.rt_render_device(ctypes.addressof(p2), buf.data_ptr(), buf.numel(), None, 0) == -1
