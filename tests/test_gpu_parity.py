@@ -679,11 +679,11 @@ def test_heavy_configs_at_larger_sizes_equal_oracle(gpu_rt, orc, which):
 
 
 @pytest.mark.parametrize("which", ["spheres256_4k_d16", "mixed1024_8k_16spp"])
-def test_benchmark_sizes_hierarchy_kernels_equal_per_object_loop(gpu_rt, which):
-    """The two heaviest benchmark configurations at their full sizes, where the CPU oracle would
-    need many minutes: the frame of the hierarchy kernels (pooled trace; for the deep one also the
-    spread and the cooperative trace) must equal the frame of the plain per-object loop, the
-    reference's algorithm as it stands, which the smaller sizes pin against the oracle."""
+def test_benchmark_sizes_hierarchy_kernels_equal_per_object_loop_and_oracle_bands(gpu_rt, orc, which):
+    """The two heaviest benchmark configurations at their full sizes: the frame of the hierarchy
+    kernels (pooled trace; for the deep one also the pilot launch and the cost order of the pixels)
+    must equal the frame of the plain per-object loop, the reference's algorithm as it stands, and
+    a seeded sample of its 16-row bands must equal the CPU oracle's rows bit for bit."""
     if which == "spheres256_4k_d16":
         scene, cam, w, h = gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 3840, 2160
         o = dict(max_depth=16, stack_size=16, shadow_hops=4, out_f32=True)
@@ -696,6 +696,21 @@ def test_benchmark_sizes_hierarchy_kernels_equal_per_object_loop(gpu_rt, which):
         assert f32_identical(fast, plain)
     else:
         assert np.array_equal(fast, plain)
+    # ... and against the CPU oracle itself on a seeded sample of 16-row bands of the full-size frame
+    # (about half a megapixel: seconds of CPU time, where the whole frame would need many minutes)
+    rng = np.random.default_rng(355)
+    nbands = h // 16
+    sample = sorted(rng.choice(nbands, size=max(1, 500000 // (16 * w)), replace=False).tolist())
+    oo = {k: v for k, v in o.items() if k != "out_f32"}
+    for band in sample:
+        y0 = band * 16                                   # GL rows (0 = bottom): output row r is GL row h - 1 - r
+        ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, rows=(y0, y0 + 16),
+                         want_f32=fast.dtype == np.float32, **oo)
+        got = fast[h - y0 - 16:h - y0][::-1]
+        if fast.dtype == np.float32:
+            assert f32_identical(got, ref["f32"]), f"{which}: band of GL rows {y0}..{y0 + 15}"
+        else:
+            assert np.array_equal(got, ref["rgba8"]), f"{which}: band of GL rows {y0}..{y0 + 15}"
 
 
 def test_largest_scene_blob_with_and_without_the_hierarchy(gpu_rt):
