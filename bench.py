@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--roofline", action="store_true",
                     help="also for the other workloads: count the frame's events with the instrumented kernel (slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inflight", action="store_true",
+                    help="skip the informational four-frames-in-flight figure (profiler runs: its overlapping launches would "
+                         "stretch the kernel's average duration in the trace)")
     ap.add_argument("--multi", default="rccl", choices=["rccl", "inlib"],
                     help="N > 1: one process per GPU with an RCCL gather (default), or one process driving all GPUs inside the library")
     args = ap.parse_args()
@@ -435,7 +438,7 @@ def main():
 
     # ---- single GPU, informational: the same frames rotating over four streams (what the N > 1 runs
     # do with their parts): the last waves of a frame, its deepest tiles, overlap the next frames
-    if world == 1 and rank == 0 and not force_gather:
+    if world == 1 and rank == 0 and not force_gather and not args.no_inflight:
         k_steps = min(args.steps, 200)
         bufs = [torch.empty_like(pipe.image) for _ in range(4)]
         s4 = [ctypes.c_void_p(s_.cuda_stream) for s_ in all_streams[:4]]

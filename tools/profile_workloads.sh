@@ -18,6 +18,4 @@ for spec in "tori64_4k 40 5 6" "spheres256_4k 4 1 4" "mixed1024_8k 3 1 3"; do
   grep '^{' gpurun_out/stats_${TAG}_$W/bench.log >> $OUT/bench_other_workloads.jsonl
   echo "$W done"
 done
-bash tools/prof_workload.sh default4k 6 > $OUT/prof_workload_default4k.txt 2>&1 || exit 1
-cp gpurun_out/pmc_default4k.json $OUT/
 ls -la $OUT
