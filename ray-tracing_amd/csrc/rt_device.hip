@@ -461,7 +461,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
         cnt.tick(HS_T_COOP);
         if (FLAT && !coop) {
-            trace_hierarchy_flat<DEBUG, TOPPOOL>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
+            trace_hierarchy_flat<DEBUG, TOPPOOL, MULTI>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
             coop = true;
 #ifdef RT_DEV_SWITCHES
             if (kp.wave_log && kp.dev_stats && active)

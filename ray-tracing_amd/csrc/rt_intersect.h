@@ -656,7 +656,8 @@ DEV void hierarchy_kept_leaves(const float *hl, const SceneLayout &L,
     leaf_lo_out = leaf_lo; leaf_hi_out = leaf_hi;
 }
 
-template <bool DEBUG>
+// queue: this lane's column of 16-bit entries, QSTRIDE entries apart (the threads of the workgroup, or the lanes of a wave)
+template <bool DEBUG, int QSTRIDE = 256>
 DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L, int polish, unsigned short *queue,
                          float ox, float oy, float oz, float dx, float dy, float dz,
                          float &best_t, int &best_id, const Counters<DEBUG> &cnt)
@@ -690,14 +691,14 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             if (!(disc.x < 0.0f)) {
                 const unsigned int sid = slot_id[2 * mp];
                 if (!(!(sid & 0x8000u) && b.x > 0.0f && b.x < 1e15f && c.x >= 0.0f)) {
-                    if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
+                    if (count < RT_QUEUE) queue[count * QSTRIDE] = (unsigned short)(sid & 0x7fffu);
                     count++;
                 }
             }
             if (!(disc.y < 0.0f)) {
                 const unsigned int sid = slot_id[2 * mp + 1];
                 if (!(!(sid & 0x8000u) && b.y > 0.0f && b.y < 1e15f && c.y >= 0.0f)) {
-                    if (count < RT_QUEUE) queue[count * 256] = (unsigned short)(sid & 0x7fffu);
+                    if (count < RT_QUEUE) queue[count * QSTRIDE] = (unsigned short)(sid & 0x7fffu);
                     count++;
                 }
             }
@@ -716,7 +717,7 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
             int mnext = 0x7fffffff;
             for (int q = 0; q < count; ++q) {
                 HSTAT(HS_SCAN);
-                int v = queue[q * 256];
+                int v = queue[q * QSTRIDE];
                 mnext = (v > last && v < mnext) ? v : mnext;
             }
             if (mnext == 0x7fffffff) break;
@@ -791,9 +792,13 @@ DEV int wave_inclusive_sum(int x)
 // ray table: origin, direction; with the pooled top-node loop also grow, slack and behind limit of the node test
 #define RT_FLAT_RAY_FIELDS(toppool) ((toppool) ? 9 : 6)
 #define RT_FLAT_DWORDS(toppool) (RT_FLAT_RAY_FIELDS(toppool) * 64 + 4 * 64 + RT_FLAT_ITEMS / 2 + RT_FLAT_CAND)
+static_assert(RT_FLAT_DWORDS(false) * 2 >= RT_QUEUE * 64, "the wave's LDS holds the candidate queues of a replay");
 static_assert(RT_FLAT_CAND >= 2 * 64 + 64 * RT_LEAF, "one round of member tests must fit next to a partial round of candidates of either kind");
 
-template <bool DEBUG, bool TOPPOOL>
+// WALK_REPLAY: the rare replay (see above) goes through the per-lane walk (trace_hierarchy) instead of over all
+// objects.  Same-call A/B: 1024 objects 8K 16 spp 998 -> 971 ms; the single-sample kernels, which run at 128
+// registers, lose 5 % with the walk inlined next to the pooled trace, so only the multi-sample ones carry it.
+template <bool DEBUG, bool TOPPOOL, bool WALK_REPLAY = false>
 DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayout &L, int polish, float *wl, bool mine,
                               float ox, float oy, float oz, float dx, float dy, float dz,
                               float &best_t, int &best_id, const Counters<DEBUG> &cnt)
@@ -1028,27 +1033,35 @@ DEV void trace_hierarchy_flat(const float *sc, const float *hl, const SceneLayou
             }
         }
     }
-    if (__ballot(replay) != 0ull) {
+    if (wave_mask(replay) != 0ull) {
         // [census: flat_replay @ 0]
         HSTAT(HS_SCAN);
         if (replay) {
-            // the reference's loop as it stands
-            const float a = dot3(dx, dy, dz, dx, dy, dz);
-            bt = 1e30f; bid = -1;
-            for (int i = 0; i < n; ++i) {
-                const float *rec = sc + 8 * (i >> 1) + (i & 1);
-                const float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
-                const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
-                const float c = oc2 - rec[6];
-                const float b = (ocz * dz + ocy * dy) + ocx * dx;
-                const float disc = b * b - c;
-                if (disc < 0.0f) continue;
-                test_candidate<DEBUG>(sc, L, polish, i, a, ocx, ocy, ocz, b, c, disc, dx, dy, dz, bt, bid, cnt);
+            if constexpr (WALK_REPLAY) {
+                // the reference's loop over the objects whose bounding test passes, in ascending index, found
+                // once more by this lane alone through the hierarchy (the wave's lists are spent by now;
+                // their LDS serves as the lane's candidate queue); ends with the ground plane like this function
+                trace_hierarchy<DEBUG, 64>(sc, hl, L, polish, reinterpret_cast<unsigned short *>(wl) + lane,
+                                           ox, oy, oz, dx, dy, dz, best_t, best_id, cnt);
+            } else {
+                // the reference's loop as it stands
+                const float a = dot3(dx, dy, dz, dx, dy, dz);
+                bt = 1e30f; bid = -1;
+                for (int i = 0; i < n; ++i) {
+                    const float *rec = sc + 8 * (i >> 1) + (i & 1);
+                    const float ocx = ox - rec[0], ocy = oy - rec[2], ocz = oz - rec[4];
+                    const float oc2 = (ocz * ocz + ocy * ocy) + ocx * ocx;
+                    const float c = oc2 - rec[6];
+                    const float b = (ocz * dz + ocy * dy) + ocx * dx;
+                    const float disc = b * b - c;
+                    if (disc < 0.0f) continue;
+                    test_candidate<DEBUG>(sc, L, polish, i, a, ocx, ocy, ocz, b, c, disc, dx, dy, dz, bt, bid, cnt);
+                }
             }
         }
     }
     // [census: flat_end @ ITER]
-    if (mine) {
+    if (mine && !(WALK_REPLAY && replay)) {
         offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
         best_t = bt; best_id = bid;
     }
