@@ -129,7 +129,7 @@ enum { PEND_REG = 0, PEND_LDS = 1, PEND_GLOBAL = 2, PEND_HYBRID = 3 };
 #define RT_WG_ONE 64
 #endif
 template <int PEND, bool DEBUG, bool REFILL> constexpr int rt_wg_size() { return (PEND == PEND_LDS && !DEBUG && !REFILL) ? RT_WG_ONE : 256; }
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false, bool WHOLE = false>
 __global__ __launch_bounds__((rt_wg_size<PEND, DEBUG, REFILL>()), (PEND == PEND_LDS || PEND == PEND_HYBRID) ? RT_WAVES_PER_EU_LDSP : (HIER && (CAP <= 7 || PEND == PEND_GLOBAL)) ? (MULTI ? RT_WAVES_PER_EU_HIER : RT_WAVES_PER_EU_HIER1) : RT_WAVES_PER_EU)
 void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ out,
                unsigned long long *__restrict__ ev_out, float *__restrict__ cap_out)
@@ -141,15 +141,20 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
     // HIER keeps only the hierarchy sections in LDS (they are what every ray reads many
     // times); bound records, materials and torus frames are read a few times per ray and
     // come from global memory through the caches, which leaves LDS room for several
-    // workgroups per CU however large the scene is.
-    const int lds_first = HIER ? L.off_top : 0;
+    // workgroups per CU however large the scene is.  WHOLE (the host's choice for scenes whose
+    // whole blob fits next to the work lists in a quarter of the CU's LDS): everything in LDS --
+    // the loads of the exact intersections and of shading then have LDS latency.
+    constexpr bool SPLIT = HIER && !WHOLE;      // hierarchy in LDS, the rest in global memory
+    const int lds_first = SPLIT ? L.off_top : 0;
     const int lds_dwords = L.total_dwords - lds_first;
     {
         const float4 *src = reinterpret_cast<const float4 *>(scene + lds_first);
         const int nq = lds_dwords >> 2;
         for (int i = threadIdx.x; i < nq; i += WG) lds4[i] = src[i];
     }
-    const float *sc = HIER ? scene : lds;       // bound records, materials, torus frames, kinds
+    const float *sc = SPLIT ? scene : lds;      // bound records, materials, torus frames, kinds
+    const float *hier = lds + ((HIER && WHOLE) ? L.off_top : 0);        // hierarchy sections (HIER)
+    (void)hier;
     Counters<DEBUG> cnt;
     cnt.lds_ev = reinterpret_cast<unsigned int *>(lds + lds_dwords);
     if constexpr (DEBUG) cnt.wave_mode = kp.wave_profile;
@@ -461,11 +466,11 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         }
         cnt.tick(HS_T_COOP);
         if (FLAT && !coop) {
-            trace_hierarchy_flat<DEBUG, TOPPOOL, MULTI>(sc, lds, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
+            trace_hierarchy_flat<DEBUG, TOPPOOL, MULTI>(sc, hier, L, kp.polish, flat_lds, active, ox, oy, oz, dx, dy, dz, t_coop, id_coop, cnt);
             coop = true;
 #ifdef RT_DEV_SWITCHES
             if (kp.wave_log && kp.dev_stats && active)
-                dev_trace_stats<DEBUG>(sc, lds, L, ox, oy, oz, dx, dy, dz, id_coop >= 0 && id_coop < L.n ? t_coop : 1e30f,
+                dev_trace_stats<DEBUG>(sc, hier, L, ox, oy, oz, dx, dy, dz, id_coop >= 0 && id_coop < L.n ? t_coop : 1e30f,
                                        state == ST_SHADOW, light_dist - travelled, cnt);
 #endif
         }
@@ -477,7 +482,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
         WCNT(WP_ITER); LCNT(WP_ITER_LANES);
         float t; int id;
         if (FLAT || (COOP && coop)) { t = t_coop; id = id_coop; }
-        else if (HIER) trace_hierarchy<DEBUG>(sc, lds, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
+        else if (HIER) trace_hierarchy<DEBUG>(sc, hier, L, kp.polish, queue, ox, oy, oz, dx, dy, dz, t, id, cnt);
         else trace_closest<DEBUG>(lds, L, kp.polish, ox, oy, oz, dx, dy, dz, t, id, cnt);
 
         bool spawn = false;     // this lane finished shading a hit: spawn children
@@ -862,7 +867,7 @@ void rt_kernel(KParams kp, const float *__restrict__ scene, void *__restrict__ o
 __global__ void reset_counters_kernel(unsigned int *counters) { counters[threadIdx.x * RT_SUBQUEUE_STRIDE] = 0u; }
 
 // ------------------------------------------------------------------ launchers
-template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false>
+template <int CAP, bool DEBUG, int PEND, bool MULTI, bool HIER, bool REFILL, bool DEEP = false, bool POOL = true, bool TOPPOOL = false, bool PILOT = false, bool WHOLE = false>
 static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, unsigned long long *d_ev,
                           float *d_cap, hipStream_t stream, LaunchInfo *info)
 {
@@ -876,8 +881,9 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     static_assert(POOL || !DEEP, "deep frames always pool");
     static_assert(!TOPPOOL || (POOL && HIER && REFILL && !DEBUG), "the pooled top-node loop is part of the pooled trace");
     static_assert(!PILOT || (HIER && REFILL && POOL && !DEEP && !MULTI && !DEBUG), "the pilot is a shallow single-sample launch of the pooled hierarchy kernel");
-    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL, TOPPOOL, PILOT>;
-    size_t lds = (size_t)(kp.scene.total_dwords - (HIER ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
+    static_assert(!WHOLE || (HIER && REFILL && !TOPPOOL && !PILOT && !DEBUG), "the whole scene in LDS is a choice of the persistent hierarchy kernels for mid-sized scenes");
+    auto kfn = rt_kernel<CAP, DEBUG, PEND, MULTI, HIER, REFILL, DEEP, POOL, TOPPOOL, PILOT, WHOLE>;
+    size_t lds = (size_t)(kp.scene.total_dwords - ((HIER && !WHOLE) ? kp.scene.off_top : 0)) * 4 + (DEBUG ? RT_COUNTER_SLOTS * 4 : 0);
     constexpr int WG = rt_wg_size<PEND, DEBUG, REFILL>();
     if (LDSP) lds = ((lds + 15) & ~(size_t)15) + (size_t)(PEND == PEND_HYBRID ? RT_HYBRID_LDS_SLOTS : CAP) * 11 * WG * 4;
     if (HIER) lds = ((lds + 15) & ~(size_t)15) + ((REFILL && !DEBUG && POOL && RT_FLAT) ? (size_t)4 * RT_FLAT_DWORDS(TOPPOOL) * 4 : (size_t)RT_QUEUE * 256 * 2);
@@ -926,6 +932,9 @@ static int launch_variant(const KParams &kp, const float *d_scene, void *d_out, 
     return 0;
 }
 
+#ifndef RT_SCENE_IN_LDS
+#define RT_SCENE_IN_LDS 1       // 0: the hierarchy kernels never stage more than the hierarchy (A/B builds)
+#endif
 // development switch (set by the host API in -DRT_DEV_SWITCHES builds only): 1 = keep the
 // pending rays of the one-pixel-per-lane kernels in registers instead of LDS (A/B runs)
 static bool dev_no_ldsp = false;
@@ -941,15 +950,26 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
     const bool deep = kp.deep != 0;
     const bool pool = kp.pooled_trace != 0;         // (the host's choice as well)
     const bool toppool = (pool || deep) && kp.pooled_top != 0;
+    // Mid-sized scenes: the whole blob in LDS when the workgroup then still takes no more than its share
+    // of the CU's LDS (a quarter; a third where the host holds the occupancy at three workgroups).
+    // Same-call A/B, everything in LDS against hierarchy only: 96 objects 4K depth 8 1.53 -> 1.45 ms, 128
+    // objects depth 4 1.09 -> 1.02 ms (per-lane lists); 64 tori 4K 1.31 -> 1.27 ms (pooled).  At the price
+    // of a workgroup per CU it loses (256 spheres 4K depth 16: 260 -> 271 ms; 284 -> 271 at equal
+    // occupancy), and with the pooled lists halved to make room it gains nothing there.
+    const size_t work_bytes = pool ? (size_t)4 * RT_FLAT_DWORDS(false) * 4 : (size_t)RT_QUEUE * 256 * 2;
+    const size_t whole_bytes = (((size_t)kp.scene.total_dwords * 4 + 15) & ~(size_t)15) + work_bytes;
+    const bool whole = RT_SCENE_IN_LDS && !toppool && whole_bytes <= (size_t)(kp.three_workgroups_per_cu ? 53 : 40) * 1024;
 #define RT_LAUNCH(CAP_, LDSP_)                                                                              \
     (multi ? launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, true, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info) \
            : launch_variant<CAP_, false, (LDSP_) ? PEND_LDS : PEND_REG, false, false, false>(kp, d_scene, d_out, nullptr, nullptr, s, info))
-#define RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, DEEP_, POOL_, TOP_) \
-    launch_variant<CAP_, false, PEND_, MULTI_, true, true, DEEP_, POOL_, TOP_>(kp, d_scene, d_out, nullptr, nullptr, s, info)
+#define RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, DEEP_, POOL_, TOP_, WHOLE_) \
+    launch_variant<CAP_, false, PEND_, MULTI_, true, true, DEEP_, POOL_, TOP_, false, WHOLE_>(kp, d_scene, d_out, nullptr, nullptr, s, info)
+#define RT_LAUNCH_HIER_W(CAP_, PEND_, MULTI_, DEEP_, POOL_) \
+    (whole ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, DEEP_, POOL_, false, true) : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, DEEP_, POOL_, false, false))
 #define RT_LAUNCH_HIER_M(CAP_, PEND_, MULTI_)                                                              \
-    (deep ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, true, true, true) : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, true, true, false)) \
-     : pool ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, true, true) : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, true, false)) \
-            : RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, false, false))
+    (deep ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, true, true, true, false) : RT_LAUNCH_HIER_W(CAP_, PEND_, MULTI_, true, true)) \
+     : pool ? (toppool ? RT_LAUNCH_HIER_V(CAP_, PEND_, MULTI_, false, true, true, false) : RT_LAUNCH_HIER_W(CAP_, PEND_, MULTI_, false, true)) \
+            : RT_LAUNCH_HIER_W(CAP_, PEND_, MULTI_, false, false))
 #define RT_LAUNCH_HIER(CAP_, PEND_) (multi ? RT_LAUNCH_HIER_M(CAP_, PEND_, true) : RT_LAUNCH_HIER_M(CAP_, PEND_, false))
     // Large scenes run as persistent waves with pixel refill (measured 1.1-2.4x there: 64 tori
     // 4K 2.43 -> 2.30 ms, 1024 objects 4K depth 4 13.4 -> 10.6 ms, 256 spheres 4K depth 16
@@ -988,6 +1008,7 @@ int launch_render(const KParams &kp, const float *d_scene, void *d_out, void *st
 #undef RT_LAUNCH_HIER
 #undef RT_LAUNCH_HIER_M
 #undef RT_LAUNCH_HIER_V
+#undef RT_LAUNCH_HIER_W
 }
 
 // The pilot launch of a deep frame (see KParams::pilot_cost): kp carries the small depth and the cost buffer.
