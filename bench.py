@@ -348,6 +348,37 @@ def main():
         frame_events = np.zeros(lib.rt_event_count(), dtype=np.uint64)
         check(lib.rt_count_events(ctypes.addressof(full), frame_events.ctypes.data))
 
+    # Every rank first has the library check its arithmetic cores on its own GPU (exhaustive over the
+    # operand ranges the kernels use: a device whose square root or division disagreed with IEEE 754
+    # would render, and so time, a different frame).  These are set-up kernels like the scene upload;
+    # they also leave the GPU at its working clocks when the warm-up steps start.
+    selftest_ok = None
+    if not args.fast_math:
+        s0 = time.perf_counter()
+        selftest_ok = not any(int(c) for c in rt355.api.selftest_math())
+        selftest_s = time.perf_counter() - s0
+
+    # ---- single GPU, informational, ahead of the timed steps (the buffers and streams it needs are
+    # set-up, and the timed steps then start on a GPU that is already at its working clocks: the first
+    # launches after an idle stretch run 5-10 % slow): the same frames rotating over four streams
+    # (what the N > 1 runs do with their parts): the last waves of a frame, its deepest tiles, overlap
+    # the next frames
+    in_flight = None
+    if world == 1 and rank == 0 and not force_gather and not args.no_inflight:
+        k_steps = 200
+        bufs = [torch.empty_like(pipe.image) for _ in range(4)]
+        s4 = [ctypes.c_void_p(s_.cuda_stream) for s_ in all_streams[:4]]
+        for i in range(8):
+            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for i in range(k_steps):
+            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
+        torch.cuda.synchronize()
+        in_flight = {"streams": 4, "steps": k_steps, "ms_per_step": (time.perf_counter() - f0) * 1e3 / k_steps,
+                     "note": "not the reported value: consecutive frames on rotating streams, host clock"}
+        del bufs
+
     run(args.warmup)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -436,21 +467,8 @@ def main():
             result["gather_only_ms_per_step"] = gather_only_ms                   # transfer alone, max over ranks
             result["part_bytes"] = int(pipe.mine[0].numel())
 
-    # ---- single GPU, informational: the same frames rotating over four streams (what the N > 1 runs
-    # do with their parts): the last waves of a frame, its deepest tiles, overlap the next frames
-    if world == 1 and rank == 0 and not force_gather and not args.no_inflight:
-        k_steps = min(args.steps, 200)
-        bufs = [torch.empty_like(pipe.image) for _ in range(4)]
-        s4 = [ctypes.c_void_p(s_.cuda_stream) for s_ in all_streams[:4]]
-        for i in range(8):
-            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
-        torch.cuda.synchronize()
-        f0 = time.perf_counter()
-        for i in range(k_steps):
-            check(lib.rt_render_device(pptr, bufs[i % 4].data_ptr(), bufs[i % 4].numel(), s4[i % 4], 0))
-        torch.cuda.synchronize()
-        result["four_frames_in_flight"] = {"streams": 4, "steps": k_steps, "ms_per_step": (time.perf_counter() - f0) * 1e3 / k_steps,
-                                           "note": "not the reported value: consecutive frames on rotating streams, host clock"}
+    if in_flight is not None:
+        result["four_frames_in_flight"] = in_flight
 
     # ---- kernel-only measurements, single GPU: roofline + cpu baseline
     if frame_events is not None:
@@ -519,6 +537,8 @@ def main():
                 result["gathered_frame_sha_ok"] = result["frame_sha_ok"]
         else:
             result["frame_sha_ok"] = None           # no llvmpipe fixture at this workload's parameters
+        if selftest_ok is not None:
+            result["arithmetic_selftest"] = {"ok": selftest_ok, "seconds": selftest_s}
         result["library"] = rt355.api.library_fingerprint()
         print(json.dumps(result))
     if use_dist:
