@@ -445,6 +445,7 @@ void build_hierarchy(const rt_object *objs, int n, SceneLayout &L, float *blob)
     }
     L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
     L.hR = std::nextafter((float)reach, INFINITY);
+    scene_test_polynomial(L);
     uint16_t *slot_id = reinterpret_cast<uint16_t *>(blob + L.off_slot_id);
     for (int sl = 0; sl < (L.n1 + 1) * RT_LEAF; ++sl) {
         float *r = blob + L.off_member + 8 * (sl >> 1) + (sl & 1);
@@ -788,6 +789,7 @@ static int pack_scene_host(const rt_object *objs, int n, SceneLayout &L_out, std
         node_sphere(objs, idx.data(), 0, n, all);
         L.hc[0] = all[0]; L.hc[1] = all[1]; L.hc[2] = all[2];
         L.hR = std::isfinite(all[3]) ? std::nextafter(all[3], INFINITY) : 0.0f;
+        scene_test_polynomial(L);
     }
     L_out = L;
     blob_out.swap(blob);

@@ -390,6 +390,14 @@ DEV void offer_plane(float oy, float dy, int n, float &bt, int &bid, const Count
     }
 }
 
+// The wave's mask of lanes in which `p` holds (the compare's own result, no detour through a 0/1
+// value), and a lane's rank among the lanes of a mask that lie below it.
+DEV unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DEV int rank_in_mask(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
 // Closest hit as (t, id): id -1 none, 0..n-1 scene object, n ground plane.
 // The bounding test (:399-402) runs on two objects per instruction with packed FP32 math
 // (v_pk_add/v_pk_mul: each half is an ordinary correctly rounded binary32 operation, so
@@ -414,28 +422,30 @@ DEV void trace_closest(const float *lds, const SceneLayout &L, int polish,
     // node test of trace_hierarchy (see there for the bound) with the scene sphere as the node, for
     // rays of near-unit direction (|a - 1| <= 1e-5, so sf^2 <= 2.5e-6 + 1.1e-5), and with
     // reach = |q| + hR replaced by the larger (|q|^2 + 1)/2 + hR, which saves the square root;
-    // (reach + grow)^2 <= 1.01 reach^2.  Its own arithmetic is free to use fma: only its slack matters.
-    bool any_object = npairs > 0;
+    // (reach + grow)^2 <= 1.01 reach^2.  Everything in it that depends on the scene alone is folded
+    // into the three coefficients L.hq on the host (scene_test_polynomial, rounded up).  Its own
+    // arithmetic is free to use fma: only its slack matters.
+    // the first pair record is requested before the test: its LDS latency passes behind the test's
+    // arithmetic (with no objects the read returns whatever follows in LDS and the loop does not run)
+    float4 A = pairs[0], B = pairs[1];
+    bool wave_skips = npairs <= 0;          // wave-uniform: no lane of the wave needs the object loop
     if (RT_SCENE_SKIP && !cnt.counting_events() && L.hR > 0.0f && n >= 3) {
-        constexpr float sf = 3.75e-3f, sf2 = 1.42e-5f;
         const float qx = ox - L.hc[0], qy = oy - L.hc[1], qz = oz - L.hc[2];
         const float q2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        const float reach = __builtin_fmaf(0.5f, q2, 0.5f + L.hR) * 1.0001f;
-        const float Re = __builtin_fmaf(sf, reach, L.hR);
-        const float slack = (2.02f * sf2) * (reach * reach) + 1e-30f;
+        const float T = __builtin_fmaf(__builtin_fmaf(L.hq[2], q2, L.hq[1]), q2, L.hq[0]);
         const float bq = __builtin_fmaf(qz, dz, __builtin_fmaf(qy, dy, qx * dx));
-        const float s = __builtin_fmaf(bq, bq, __builtin_fmaf(Re, Re, slack) - q2);
-        const bool near_unit = __builtin_fabsf(a - 1.0f) <= 1e-5f;
-        any_object = !(near_unit && s < 0.0f);       // NaN keeps the loop
+        const float s = __builtin_fmaf(bq, bq, T - q2);
+        // a lane skips if its direction is near unit length and s < 0 (a NaN keeps the loop); lane masks
+        // straight from the two compares
+        const unsigned long long skip = wave_mask(__builtin_fabsf(a - 1.0f) <= 1e-5f) & wave_mask(s < 0.0f);
+        wave_skips = skip == wave_mask(true);
     }
 #if RT_PAIR_PACKED
     const v2f OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
     const v2f DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz};
 #endif
-    float4 A = make_float4(0, 0, 0, 0), B = A;
-    if (__ballot(any_object) == 0ull) { WCNT(WP_SCENE_SKIP); }
+    if (wave_skips) { WCNT(WP_SCENE_SKIP); }
     else {
-    if (npairs > 0) { A = pairs[0]; B = pairs[1]; }
     for (int j = 0; j < npairs; ++j) {
         // [census: pair_test @ PAIR]
         WCNT(WP_PAIR);
@@ -739,14 +749,6 @@ DEV void trace_hierarchy(const float *sc, const float *hl, const SceneLayout &L,
     }
     offer_plane<DEBUG>(oy, dy, n, bt, bid, cnt);
     best_t = bt; best_id = bid;
-}
-
-// The wave's mask of lanes in which `p` holds (the compare's own result, no detour through a 0/1
-// value), and a lane's rank among the lanes of a mask that lie below it.
-DEV unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-DEV int rank_in_mask(unsigned long long m)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
 }
 
 // Inclusive prefix sum over the 64 lanes in six VALU instructions with DPP operands (shifts inside

@@ -31,8 +31,25 @@ struct SceneLayout {
     int n1, n2;         // leaf / top nodes of the sphere hierarchy (0: none)
     int off_top, off_leaf, off_member, off_slot_id;
     float hc[3], hR;    // sphere that contains every object's bounding sphere and every node
+    float hq[3];        // the per-object loop's scene-sphere test as a polynomial in |o - hc|^2 (see scene_test_polynomial)
     int total_dwords;   // padded to a multiple of 4
 };
+
+// The scene-sphere test of the per-object loop (trace_closest) asks whether a ray of near-unit direction d
+// from o can pass any object's binary32 bounding test: with q = o - hc it keeps the loop unless
+//   (q.d)^2 + T(|q|^2) - |q|^2 < 0,   T = (hR + sf u)^2 + 2.02 sf2 u^2 + 1e-30,   u = 1.0001 (|q|^2 / 2 + 1/2 + hR)
+// (u bounds the distance |q| + hR to the far side of the sphere without a square root; sf, sf2: the slack
+// of the node tests for directions with | |d|^2 - 1 | <= 1e-5).  T is a quadratic polynomial in |q|^2 with
+// positive coefficients; they are computed here in double precision and rounded up with a relative margin
+// of 1e-5, far above the two roundings of its evaluation with fused multiply-adds, so the kernel's value
+// is never below T.
+static inline void scene_test_polynomial(SceneLayout &L)
+{
+    const double sf = 3.75e-3, sf2 = 1.42e-5, hR = (double)L.hR;
+    const double g = sf * sf + 2.02 * sf2, k0 = 1.0001 * (0.5 + hR), k1 = 1.0001 * 0.5;
+    const double c[3] = {hR * hR + 2.0 * hR * sf * k0 + g * k0 * k0 + 1e-30, 2.0 * hR * sf * k1 + 2.0 * g * k0 * k1, g * k1 * k1};
+    for (int i = 0; i < 3; ++i) L.hq[i] = (float)(c[i] * (1.0 + 1e-5)) * 1.000001f;
+}
 
 #define RT_LEAF 8        // object slots per leaf node (even)
 #define RT_FAN 8         // leaf nodes per top node (even)
@@ -55,6 +72,7 @@ static inline SceneLayout scene_layout(int n, int ntori, bool hierarchy)
     int end = (L.off_kind + n + 3) & ~3;
     L.n1 = L.n2 = 0;
     L.hc[0] = L.hc[1] = L.hc[2] = 0.0f; L.hR = 0.0f;
+    L.hq[0] = L.hq[1] = L.hq[2] = 0.0f;
     L.off_top = L.off_leaf = L.off_member = L.off_slot_id = end;
     if (hierarchy) {
         L.n1 = (n + RT_LEAF - 1) / RT_LEAF;
