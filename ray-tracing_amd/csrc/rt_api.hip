@@ -320,7 +320,7 @@ int coop_rays_for(int n)
 }
 
 // the hierarchy walk keeps its lists of kept nodes in bit masks: 128 leaf nodes, 32 top nodes
-static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && (RT_FAN == 8 || RT_FAN == 4),
+static_assert(RT_MAX_OBJECTS <= 128 * RT_LEAF && RT_MAX_OBJECTS <= 32 * RT_LEAF * RT_FAN && RT_FAN == 8,
               "node masks of trace_hierarchy are sized for this");
 static_assert(RT_MAX_OBJECTS <= 32768, "slot ids keep the object index in 15 bits (bit 15 flags a torus)");
 static_assert(RT_MAX_OBJECTS / RT_LEAF + 1 <= 256, "the pooled trace's (ray, leaf) items hold the leaf number, or that of the empty leaf behind the last one, in 8 bits");

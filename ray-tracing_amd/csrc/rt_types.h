@@ -52,9 +52,7 @@ static inline void scene_test_polynomial(SceneLayout &L)
 }
 
 #define RT_LEAF 8        // object slots per leaf node (even)
-#ifndef RT_FAN
-#define RT_FAN 8         // leaf nodes per top node (4 or 8)
-#endif
+#define RT_FAN 8         // leaf nodes per top node (even)
 #define RT_SUBQUEUES 32        // interleaved sub-queues of the persistent-wave work queue, one counter each
 #define RT_SUBQUEUE_STRIDE 64   // dwords between two counters (each on its own 256-byte line)
 #define RT_PEND_MAX 16   // pending-ray slots per lane in the global workspace (= RT_MAX_PENDING)
