@@ -379,6 +379,13 @@ def main():
                      "note": "not the reported value: consecutive frames on rotating streams, host clock"}
         del bufs
 
+    # N > 1 (no four-streams figure there): the same number of untimed frames through the pipeline, for the
+    # same reason -- working clocks, and RCCL's first collectives (connection set-up) out of the way
+    preroll = 0
+    if use_dist:
+        preroll = 200
+        run(preroll)
+
     run(args.warmup)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -466,6 +473,7 @@ def main():
             result["host_issue_ms_per_step"] = host_issue_s * 1e3 / args.steps   # rank 0's enqueue cost
             result["gather_only_ms_per_step"] = gather_only_ms                   # transfer alone, max over ranks
             result["part_bytes"] = int(pipe.mine[0].numel())
+            result["untimed_frames_before_warmup"] = preroll
 
     if in_flight is not None:
         result["four_frames_in_flight"] = in_flight
