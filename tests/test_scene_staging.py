@@ -96,3 +96,31 @@ def test_staging_rejects_what_set_scene_rejects(rt):
         rt.stage_scene_host(bad)
     L, blob, _ = rt.stage_scene_host([])
     assert L["n"] == 0 and L["n1"] == 0
+
+
+def test_scene_sphere_polynomial_bounds_the_direct_form():
+    """The per-object loop skips rays that miss the sphere around the scene.  The kernel evaluates the
+    scene-only part of that test, T(|q|^2) = (hR + sf u)^2 + 2.02 sf2 u^2 + 1e-30 with
+    u = 1.0001 (|q|^2 / 2 + 1/2 + hR), as a quadratic polynomial with three host-computed coefficients
+    (scene_test_polynomial in csrc/rt_types.h: exact coefficients times 1 + 1e-5, rounded to binary32,
+    times 1.000001) and two fused multiply-adds.  The test must stay conservative, i.e. the binary32
+    polynomial value may never fall below the exact T: restated here and checked over the ranges of
+    scene radius and origin distance the renderer meets."""
+    rng = np.random.default_rng(5)
+    sf, sf2 = 3.75e-3, 1.42e-5
+    hR = np.exp(rng.uniform(np.log(1e-3), np.log(1e6), 20000))
+    hR = np.float32(hR).astype(np.float64)                        # the kernel parameter is a binary32 value
+    q2 = np.float32(np.exp(rng.uniform(np.log(1e-6), np.log(1e14), 20000))).astype(np.float64)
+    g, k0, k1 = sf * sf + 2.02 * sf2, 1.0001 * (0.5 + hR), 1.0001 * 0.5
+    exact = [hR * hR + 2 * hR * sf * k0 + g * k0 * k0 + 1e-30, 2 * hR * sf * k1 + 2 * g * k0 * k1, np.full_like(hR, g * k1 * k1)]
+    c0, c1, c2 = (np.float32(np.float32(c * (1.0 + 1e-5)) * np.float32(1.000001)) for c in exact)
+    # fused multiply-add in binary32 = the exact product-sum (representable in float64 for these magnitudes
+    # up to a relative 1e-16) rounded once
+    inner = np.float32(c2.astype(np.float64) * q2 + c1.astype(np.float64))
+    t_kernel = np.float32(inner.astype(np.float64) * q2 + c0.astype(np.float64)).astype(np.float64)
+    u = 1.0001 * (0.5 * q2 + 0.5 + hR)
+    t_exact = (hR + sf * u) ** 2 + 2.02 * sf2 * u * u + 1e-30
+    finite = np.isfinite(t_kernel)
+    assert finite.mean() > 0.9
+    assert np.all(t_kernel[finite] >= t_exact[finite])
+    assert np.all(t_kernel[finite] <= t_exact[finite] * (1 + 3e-5))      # and no looser than the margin it was given
