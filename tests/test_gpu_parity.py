@@ -550,6 +550,32 @@ def test_hierarchy_equals_per_object_loop_random_large(gpu_rt, orc, seed):
         assert f32_identical(small, ref), f"seed {seed}: n={len(scene)} {o}"
 
 
+@pytest.mark.parametrize("case", ["lists", "lists_spp2", "tori_pooled", "tori_pooled_spp2", "deep", "deep_256_spheres"])
+def test_mid_sized_scenes_with_the_whole_scene_in_lds(gpu_rt, orc, case):
+    """Hierarchy kernels of scenes whose blob fits next to the work lists in a quarter of a CU's LDS (a third
+    for small deep frames) stage all of it there, not only the hierarchy sections: one instantiation each for
+    per-lane lists / pooled trace, one / several samples per pixel, deep frames.  Frames equal the per-object
+    loop's and the oracle's bit for bit, and the launch's LDS size shows that the variant ran."""
+    scene, cam, w, h, o = {
+        "lists": (gpu_rt.mixed_scene(120, seed=3), gpu_rt.mixed_camera(), 200, 112, dict(max_depth=6, stack_size=5, shadow_hops=2)),
+        "lists_spp2": (gpu_rt.mixed_scene(120, seed=3), gpu_rt.mixed_camera(), 120, 68, dict(max_depth=5, stack_size=3, shadow_hops=2, spp_grid=2)),
+        "tori_pooled": (gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera(), 200, 112, dict(max_depth=8, stack_size=3, shadow_hops=2)),
+        "tori_pooled_spp2": (gpu_rt.tori_stress_scene(), gpu_rt.tori_stress_camera(), 120, 68, dict(max_depth=4, stack_size=3, shadow_hops=2, spp_grid=2)),
+        "deep": (gpu_rt.mixed_scene(150, seed=9), gpu_rt.mixed_camera(), 160, 90, dict(max_depth=12, stack_size=9, shadow_hops=2)),
+        "deep_256_spheres": (gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 160, 90, dict(max_depth=16, stack_size=16, shadow_hops=4)),
+    }[case]
+    fast, plain = _accel_vs_plain(gpu_rt, scene, cam, w, h, **o)
+    assert f32_identical(fast, plain), f"{case}: n={len(scene)} {o}"
+    ref = orc.render(scene, cam.matrix(), cam.focal_length, w, h, light=cam.light_pos, want_f32=True, **o)["f32"]
+    assert f32_identical(fast, ref), f"{case}: n={len(scene)} {o}"
+    gpu_rt.render_rgba(scene, cam, w, h, bottom_up=True, out_f32=True, **o)
+    lds = gpu_rt.timing()["lds_bytes"]
+    blob_bytes = (4 * gpu_rt.stage_scene_host(scene)[0]["total_dwords"] + 15) & ~15
+    per_lane_queue, pooled_lists, three_per_cu = 32 * 256 * 2, 4 * 1792 * 4, 41 * 1024
+    assert lds in (blob_bytes + per_lane_queue, blob_bytes + pooled_lists, three_per_cu), (case, lds, blob_bytes)
+    assert lds >= blob_bytes + per_lane_queue
+
+
 def test_hierarchy_equals_per_object_loop_named_scenes(gpu_rt):
     for scene, cam, w, h, o in [
         (gpu_rt.spheres_deep_scene(), gpu_rt.spheres_deep_camera(), 480, 270, dict(max_depth=16, stack_size=16, shadow_hops=4)),
